@@ -1,0 +1,165 @@
+/*
+ * lbm_abi.h -- C ABI of liblbm_hip.so: the MI355X (gfx950) kernels of the batched EEG epoch
+ * pipeline (band-pass FIR -> ICA apply -> epoch post-processing -> Welch PSD -> band powers ->
+ * VQ-VAE encoder -> nearest-codebook tokenisation).
+ *
+ * The reference (beetleberries/LBM) is pure Python and has no FFI; each entry point below names the
+ * reference call site (file:line under /root/reference) whose arithmetic it replaces.  The
+ * reference-side binding is a ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is CALLER-OWNED DEVICE memory (hipMalloc / torch CUDA tensor data_ptr());
+ *     the library never allocates, frees or synchronises; scratch is passed in explicitly;
+ *   - tensors are row-major with the innermost dimension contiguous, float32 unless stated;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: LBM_OK (0) or a negative LBM_E* code; lbm_last_error() gives a thread-local
+ *     human-readable message for the last failing call on this thread.  Nothing ever exit()s or
+ *     throws across the ABI (contrast the reference scripts' exit() calls);
+ *   - empty inputs (rows == 0, E == 0, N == 0) are valid no-ops.
+ */
+#ifndef LBM_ABI_H
+#define LBM_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_ABI_VERSION 1
+
+#define LBM_OK 0
+#define LBM_EINVAL (-1)       /* bad argument (NULL pointer, non-positive size, misaligned, ...) */
+#define LBM_EUNSUPPORTED (-2) /* argument combination outside what the kernels implement */
+#define LBM_ELAUNCH (-3)      /* HIP reported an error when launching */
+
+typedef void* lbm_stream_t;
+
+int lbm_version(void);
+const char* lbm_last_error(void);
+
+/* ---- a1 / a2: zero-phase FIR ------------------------------------------------------------------
+ * Replaces mne raw.filter(l_freq=4, h_freq=30, fir_design='firwin') at training/preprocess.py:77,
+ * multi-train/withpsd.py:118, preprocessing_unsupervised.py:36, and raw.notch_filter(...) at
+ * training/preprocess.py:82, multi-train/withpsd.py:119 (same machinery, different taps).
+ * y[r, n] = sum_k taps[k] * xpad[r, n + (ntaps-1) - k], xpad = x padded by (ntaps-1)/2 per side.
+ * x, y: [rows, T]; taps: [ntaps] device floats, ntaps odd (type-I, delay (ntaps-1)/2 removed).
+ * pad_mode: LBM_PAD_REFLECT_LIMITED = MNE 'reflect_limited' (odd reflection 2*x[0]-x[m], zero where
+ * reflection runs out of samples); LBM_PAD_ZERO = zero padding.  x and y must not overlap. */
+#define LBM_PAD_REFLECT_LIMITED 0
+#define LBM_PAD_ZERO 1
+int lbm_fir_f32(const float* x, float* y, int64_t rows, int32_t T, const float* taps, int32_t ntaps,
+                int32_t pad_mode, lbm_stream_t stream);
+
+/* ---- a3: per-sample channel affine map (ICA apply / unmix / average reference) -------------------
+ * Replaces ica.apply(raw, exclude=...) at training/preprocess.py:144, multi-train/withpsd.py:152,
+ * preprocessing_unsupervised.py:41 (and get_sources, set_eeg_reference('average') :35), folded to
+ * y[e, o, t] = sum_c A[o, c] * x[e, c, t] + b[o].
+ * x: [E, Cin, T]; y: [E, Cout, T]; A: [Cout, Cin]; b: [Cout] or NULL.  1 <= Cin, Cout <= 256.
+ * x and y must not overlap. */
+int lbm_affine_ch_f32(const float* x, float* y, int64_t E, int32_t Cin, int32_t Cout, int32_t T,
+                      const float* A, const float* b, lbm_stream_t stream);
+
+/* ---- a4 / a5 / a6: epoch post-processing ----------------------------------------------------------
+ * Replaces mne.Epochs(..., baseline=(None, 0)) baseline correction (training/preprocess.py:262-271),
+ * reject=dict(eeg=150e-6)+drop_bad (multi-train/withpsd.py:44-46,213-219) and the per-epoch
+ * per-channel z-score (training/preprocess.py:279-287).
+ * For every (epoch, channel) row of x[E, C, T]:
+ *   base  = mean(x[:n_baseline])            (n_baseline == 0: no baseline correction)
+ *   y_base = x - base                        (written when y_base != NULL; may alias x)
+ *   keep[e] = 0 if any channel has max-min > ptp_thresh, else 1 (written when keep != NULL)
+ *   y_std = (y_base - mean_t) / (std_t + eps), population std (written when y_std != NULL and
+ *            standardize_mode == LBM_STD_EPOCH_CHANNEL; y_std may alias x)
+ * T <= 40960. */
+#define LBM_STD_NONE 0
+#define LBM_STD_EPOCH_CHANNEL 1
+int lbm_epoch_post_f32(const float* x, float* y_base, float* y_std, uint8_t* keep, int64_t E, int32_t C,
+                       int32_t T, int32_t n_baseline, float ptp_thresh, int32_t standardize_mode, float eps,
+                       lbm_stream_t stream);
+
+/* mne.decoding.Scaler(scalings='mean') (multi-train/withpsd.py:267-270) = fit + transform:
+ * lbm_channel_moments_f32: moments[c] = {sum, sum of squares, sample count} in float64 over all kept
+ *   epochs x time (keep == NULL: all epochs), reduced in a fixed order (deterministic).
+ *   row_ws: scratch, E*C*2 doubles.  moments: [C, 3] doubles.
+ * lbm_channel_scale_f32:  y[e,c,t] = (x[e,c,t] - mean[c]) / scale[c]  (may run in place). */
+int lbm_channel_moments_f32(const float* x, const uint8_t* keep, double* row_ws, double* moments, int64_t E,
+                            int32_t C, int32_t T, lbm_stream_t stream);
+int lbm_channel_scale_f32(const float* x, float* y, const float* mean, const float* scale, int64_t E,
+                          int32_t C, int32_t T, lbm_stream_t stream);
+
+/* ---- a7: Welch PSD ----------------------------------------------------------------------------------
+ * Replaces epochs.compute_psd(method='welch', fmin, fmax, n_fft, window, n_overlap, average) +
+ * spectrum.get_data() at multi-train/withpsd.py:236-250 and raw.compute_psd(fmin, fmax, n_fft=512) at
+ * preprocessing_unsupervised.py:43 (MNE psd_array_welch -> scipy.signal.spectrogram semantics:
+ * per-segment mean removal, periodic window, rFFT of length nfft, |X|^2 / (fs * sum(w^2)), x2 for all
+ * bins except DC and (even nfft) Nyquist, then the average over segments).
+ *
+ * Tables: lbm_welch_tables_bytes() gives the size of a caller-owned device buffer that
+ * lbm_welch_tables_init() fills (window, twiddles and the folded DFT basis for bins bin_lo..bin_hi,
+ * evaluated in float64 on the device and rounded once).  The same buffer then serves every
+ * lbm_welch_f32 call with the same (nfft, nperseg, window_id, bin_lo, bin_hi).
+ * x: [rows, T]; psd: [rows, F] with F = bin_hi - bin_lo + 1 (bins are rFFT indices, inclusive);
+ * seg_or_null: [rows, F, nseg] per-segment spectra (MNE average=None), nseg = (T-noverlap)/(nperseg-noverlap);
+ * average_mode: LBM_AVG_MEAN | LBM_AVG_MEDIAN (scipy median-bias corrected) | LBM_AVG_NONE (psd may be NULL).
+ * Requires nperseg <= nfft <= T, 0 <= noverlap < nperseg, 0 <= bin_lo <= bin_hi <= nfft/2. */
+#define LBM_WIN_BOXCAR 0
+#define LBM_WIN_HANN 1
+#define LBM_WIN_HAMMING 2
+#define LBM_AVG_MEAN 0
+#define LBM_AVG_MEDIAN 1
+#define LBM_AVG_NONE 2
+size_t lbm_welch_tables_bytes(int32_t nfft, int32_t nperseg, int32_t bin_lo, int32_t bin_hi);
+int lbm_welch_tables_init(void* tables, int32_t nfft, int32_t nperseg, int32_t window_id, int32_t bin_lo,
+                          int32_t bin_hi, lbm_stream_t stream);
+int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int64_t rows, int32_t T, float fs,
+                  int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
+                  int32_t bin_hi, int32_t average_mode, lbm_stream_t stream);
+
+/* ---- a8: theta/alpha/beta band powers and ratios ----------------------------------------------------
+ * Replaces preprocessing_unsupervised.py:45-61 (also :102-110, failed/label.py:13-23):
+ * log = 10*log10(psd) (skipped when already_db), theta = mean over channels x bins with 4<=f<8,
+ * alpha 8<=f<13, beta 13<=f<30; out = {theta, alpha, beta, beta/theta, alpha/beta, theta/beta}
+ * (ratios of the dB means, as the reference computes them).
+ * psd: [E, C, F]; freqs: [F] device floats; out: [E, 6] (per_channel == 0) or [E, C, 6]. */
+int lbm_bandpower_f32(const float* psd, const float* freqs, float* out, int64_t E, int32_t C, int32_t F,
+                      int32_t per_channel, int32_t already_db, lbm_stream_t stream);
+
+/* ---- a10: VQ-VAE encoder convolution ----------------------------------------------------------------
+ * Replaces one nn.Conv1d(+ReLU) of VQVAE.encoder, training/model.py:169-177 (used by encode :208).
+ * x: [B, Cin, Lin]; w: [Cout, Cin, ksize] (torch layout); bias: [Cout] or NULL;
+ * y: [B, Cout, Lout], Lout = (Lin + 2*pad - ksize)/stride + 1.  fp32 MFMA, exact fp32 fmaf chains. */
+int lbm_conv1d_f32(const float* x, const float* w, const float* bias, float* y, int64_t B, int32_t Cin,
+                   int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
+                   lbm_stream_t stream);
+
+/* ---- a12 / a13: codebook distance + argmin ----------------------------------------------------------
+ * Replaces VectorQuantizerEMA.get_code_indices, training/model.py:152-158 (same math in forward :90-95):
+ * d[n,k] = (sum(x_n^2) + sum(e_k^2)) - 2 * (x_n . e_k) in fp32, idx[n] = first k attaining the minimum.
+ * The [N,K] distance matrix is never written to memory.
+ * layout LBM_VQ_ROWS: x is [N, D] with row stride ldx (floats);
+ * layout LBM_VQ_CHANNEL_MAJOR: x is the encoder output z[B, D, S] (N = B*S, row n = (b = n / S, s = n % S)),
+ *   which removes the permute(0,2,1).contiguous() of training/model.py:209; ldx must be S.
+ * codebook: [K, D]; e_sqnorm: [K] = lbm_rownorm2_f32(codebook); idx_out: [N] int64;
+ * mind_or_null: [N] minimum distance; hist_or_null: [K] usage counts, ADDED to (caller zeroes).
+ * D must be a multiple of 8 and <= 256; K >= 1. */
+#define LBM_VQ_ROWS 0
+#define LBM_VQ_CHANNEL_MAJOR 1
+int lbm_rownorm2_f32(const float* m, float* out, int64_t rows, int32_t D, lbm_stream_t stream);
+int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, const float* codebook,
+                      const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
+                      unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
+
+/* VectorQuantizerEMA.forward tail, training/model.py:100,130-139: quantized = E[idx] (returned with the
+ * straight-through arithmetic x + (E[idx] - x)), sq_err_sum[0] += sum((E[idx] - x)^2) in float64
+ * (caller zeroes; mse = sq_err_sum / (N*D); loss = (1 + commitment_cost) * mse in the forward pass). */
+int lbm_vq_gather_loss_f32(const float* x, const float* codebook, const int64_t* idx, float* quantized,
+                           double* sq_err_sum, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
+
+/* training/model.py:142-144: perplexity = exp(-sum(p * log(p + 1e-10))), p = hist / sum(hist). out: [1]. */
+int lbm_perplexity_u64(const unsigned long long* hist, float* out, int32_t K, lbm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_ABI_H */

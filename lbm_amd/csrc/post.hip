@@ -1,0 +1,213 @@
+// Epoch post-processing (a4/a5/a6): baseline correction, peak-to-peak rejection mask, z-score.
+//
+// HBM-bound, one read + up to two writes per sample.  TPR threads cooperate on one (epoch, channel)
+// row and keep it in registers (NV values per thread), so the row is read from HBM exactly once:
+// TPR = 64 (one wavefront per row, shuffle reductions only, no barrier) up to T = 2560, a 256- or
+// 1024-thread workgroup per row beyond that.  Two-pass mean/variance in fp32 on register data.
+#include "common.h"
+
+namespace {
+
+constexpr int kNV = 40;
+
+template <int TPR>
+__device__ __forceinline__ float row_reduce(float v, int op, float* s_red) {
+    // op: 0 sum, 1 min, 2 max.  TPR == 64: wavefront only.  Otherwise all waves of the block = one row.
+    v = (op == 0) ? lbm::wave_sum(v) : (op == 1) ? lbm::wave_min(v) : lbm::wave_max(v);
+    if constexpr (TPR > 64) {
+        constexpr int NW = TPR / 64;
+        const int w = threadIdx.x >> 6;
+        __syncthreads();  // s_red free
+        if ((threadIdx.x & 63) == 0) s_red[w] = v;
+        __syncthreads();
+        float r = s_red[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) r = (op == 0) ? r + s_red[i] : (op == 1) ? fminf(r, s_red[i]) : fmaxf(r, s_red[i]);
+        v = r;
+    }
+    return v;
+}
+
+template <int TPR, int NV>
+__global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void post_kernel(const float* __restrict__ x, float* y_base,
+                                                                      float* y_std, uint8_t* __restrict__ keep,
+                                                                      int64_t rows, int C, int T, int nb,
+                                                                      float thresh, int std_mode, float eps) {
+    __shared__ float s_red[16];
+    constexpr int BLOCK = TPR < 256 ? 256 : TPR;
+    constexpr int RPB = BLOCK / TPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+    if (row >= rows) return;  // uniform per row group (wave when TPR == 64, block otherwise)
+    const int l = threadIdx.x % TPR;
+    const float* xr = x + row * (int64_t)T;
+
+    float v[NV];
+    float bsum = 0.f, tsum = 0.f, vmin = INFINITY, vmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int t = i * TPR + l;
+        v[i] = 0.f;
+        if (t < T) {
+            v[i] = xr[t];
+            tsum += v[i];
+            if (t < nb) bsum += v[i];
+            vmin = fminf(vmin, v[i]);
+            vmax = fmaxf(vmax, v[i]);
+        }
+    }
+    tsum = row_reduce<TPR>(tsum, 0, s_red);
+    vmin = row_reduce<TPR>(vmin, 1, s_red);
+    vmax = row_reduce<TPR>(vmax, 2, s_red);
+    float base = 0.f;
+    if (nb > 0) base = row_reduce<TPR>(bsum, 0, s_red) / (float)nb;
+
+    if (keep != nullptr && l == 0 && (vmax - vmin) > thresh) keep[row / C] = 0;
+
+    const float mean = tsum / (float)T - base;  // mean of the baseline-corrected row
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int t = i * TPR + l;
+        if (t < T) {
+            v[i] -= base;
+            if (y_base != nullptr) y_base[row * (int64_t)T + t] = v[i];
+            const float d = v[i] - mean;
+            ss = fmaf(d, d, ss);
+        }
+    }
+    if (y_std == nullptr || std_mode != LBM_STD_EPOCH_CHANNEL) return;
+    ss = row_reduce<TPR>(ss, 0, s_red);
+    const float denom = sqrtf(ss / (float)T) + eps;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int t = i * TPR + l;
+        if (t < T) y_std[row * (int64_t)T + t] = (v[i] - mean) / denom;
+    }
+}
+
+// one wavefront per (epoch, channel) row: float64 sum and sum of squares
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep,
+                                                          double* __restrict__ row_ws, int64_t rows, int C, int T) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int l = threadIdx.x & 63;
+    double s = 0.0, q = 0.0;
+    if (keep == nullptr || keep[row / C]) {
+        const float* xr = x + row * (int64_t)T;
+        for (int t = l; t < T; t += 64) {
+            const double v = (double)xr[t];
+            s += v;
+            q = fma(v, v, q);
+        }
+    }
+    s = lbm::wave_sum(s);
+    q = lbm::wave_sum(q);
+    if (l == 0) {
+        row_ws[2 * row] = s;
+        row_ws[2 * row + 1] = q;
+    }
+}
+
+// one workgroup per channel: fixed-order reduction over epochs -> deterministic moments
+__global__ __launch_bounds__(256) void channel_moments_kernel(const double* __restrict__ row_ws,
+                                                              const uint8_t* __restrict__ keep,
+                                                              double* __restrict__ moments, int64_t E, int C, int T) {
+    __shared__ double s_s[4], s_q[4], s_n[4];
+    const int c = blockIdx.x;
+    double s = 0.0, q = 0.0, n = 0.0;
+    for (int64_t e = threadIdx.x; e < E; e += 256) {
+        if (keep == nullptr || keep[e]) {
+            s += row_ws[2 * (e * C + c)];
+            q += row_ws[2 * (e * C + c) + 1];
+            n += (double)T;
+        }
+    }
+    s = lbm::wave_sum(s);
+    q = lbm::wave_sum(q);
+    n = lbm::wave_sum(n);
+    if ((threadIdx.x & 63) == 0) {
+        s_s[threadIdx.x >> 6] = s;
+        s_q[threadIdx.x >> 6] = q;
+        s_n[threadIdx.x >> 6] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        moments[3 * c + 0] = (s_s[0] + s_s[1]) + (s_s[2] + s_s[3]);
+        moments[3 * c + 1] = (s_q[0] + s_q[1]) + (s_q[2] + s_q[3]);
+        moments[3 * c + 2] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void channel_scale_kernel(const float* x, float* y, const float* __restrict__ mean,
+                                                            const float* __restrict__ scale, int64_t rows, int C, int T) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int c = (int)(row % C);
+    const float m = mean[c], s = scale[c];
+    for (int t = threadIdx.x & 63; t < T; t += 64) y[row * (int64_t)T + t] = (x[row * (int64_t)T + t] - m) / s;
+}
+
+template <int TPR>
+int launch_post(const float* x, float* y_base, float* y_std, uint8_t* keep, int64_t rows, int C, int T, int nb,
+                float thresh, int std_mode, float eps, hipStream_t st) {
+    constexpr int BLOCK = TPR < 256 ? 256 : TPR;
+    constexpr int RPB = BLOCK / TPR;
+    const int64_t blocks = (rows + RPB - 1) / RPB;
+    if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_epoch_post_f32: grid too large");
+    hipLaunchKernelGGL((post_kernel<TPR, kNV>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, x, y_base, y_std, keep, rows,
+                       C, T, nb, thresh, std_mode, eps);
+    return lbm::check_launch("lbm_epoch_post_f32");
+}
+
+}  // namespace
+
+extern "C" int lbm_epoch_post_f32(const float* x, float* y_base, float* y_std, uint8_t* keep, int64_t E, int32_t C,
+                                  int32_t T, int32_t n_baseline, float ptp_thresh, int32_t standardize_mode, float eps,
+                                  lbm_stream_t stream) {
+    LBM_REQUIRE(E >= 0 && C >= 1 && T >= 0, LBM_EINVAL, "lbm_epoch_post_f32: bad sizes (E=%lld C=%d T=%d)", (long long)E, C, T);
+    LBM_REQUIRE(n_baseline >= 0 && n_baseline <= T, LBM_EINVAL, "lbm_epoch_post_f32: n_baseline=%d outside [0,%d]", n_baseline, T);
+    LBM_REQUIRE(standardize_mode == LBM_STD_NONE || standardize_mode == LBM_STD_EPOCH_CHANNEL, LBM_EINVAL,
+                "lbm_epoch_post_f32: unknown standardize_mode %d", standardize_mode);
+    if (E == 0) return LBM_OK;
+    hipStream_t st = lbm::as_stream(stream);
+    if (keep != nullptr) {
+        hipError_t e = hipMemsetAsync(keep, 1, (size_t)E, st);
+        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_epoch_post_f32: memset keep: %s", hipGetErrorString(e));
+    }
+    if (T == 0) return LBM_OK;
+    LBM_REQUIRE(x != nullptr, LBM_EINVAL, "lbm_epoch_post_f32: NULL x");
+    LBM_REQUIRE(T <= 1024 * kNV, LBM_EUNSUPPORTED, "lbm_epoch_post_f32: T=%d > %d", T, 1024 * kNV);
+    const int64_t rows = E * C;
+    if (T <= 64 * kNV) return launch_post<64>(x, y_base, y_std, keep, rows, C, T, n_baseline, ptp_thresh, standardize_mode, eps, st);
+    if (T <= 256 * kNV) return launch_post<256>(x, y_base, y_std, keep, rows, C, T, n_baseline, ptp_thresh, standardize_mode, eps, st);
+    return launch_post<1024>(x, y_base, y_std, keep, rows, C, T, n_baseline, ptp_thresh, standardize_mode, eps, st);
+}
+
+extern "C" int lbm_channel_moments_f32(const float* x, const uint8_t* keep, double* row_ws, double* moments, int64_t E,
+                                       int32_t C, int32_t T, lbm_stream_t stream) {
+    LBM_REQUIRE(E >= 0 && C >= 1 && T >= 0, LBM_EINVAL, "lbm_channel_moments_f32: bad sizes");
+    LBM_REQUIRE(moments != nullptr, LBM_EINVAL, "lbm_channel_moments_f32: NULL moments");
+    LBM_REQUIRE(E == 0 || (x != nullptr && row_ws != nullptr), LBM_EINVAL, "lbm_channel_moments_f32: NULL pointer");
+    hipStream_t st = lbm::as_stream(stream);
+    const int64_t rows = E * C;
+    if (rows > 0) {
+        const int64_t blocks = (rows + 3) / 4;
+        LBM_REQUIRE(blocks <= 0x7fffffffLL, LBM_EUNSUPPORTED, "lbm_channel_moments_f32: grid too large");
+        hipLaunchKernelGGL(row_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, keep, row_ws, rows, C, T);
+    }
+    hipLaunchKernelGGL(channel_moments_kernel, dim3(C), dim3(256), 0, st, row_ws, keep, moments, E, C, T);
+    return lbm::check_launch("lbm_channel_moments_f32");
+}
+
+extern "C" int lbm_channel_scale_f32(const float* x, float* y, const float* mean, const float* scale, int64_t E,
+                                     int32_t C, int32_t T, lbm_stream_t stream) {
+    LBM_REQUIRE(E >= 0 && C >= 1 && T >= 0, LBM_EINVAL, "lbm_channel_scale_f32: bad sizes");
+    if (E == 0 || T == 0) return LBM_OK;
+    LBM_REQUIRE(x && y && mean && scale, LBM_EINVAL, "lbm_channel_scale_f32: NULL pointer");
+    const int64_t rows = E * C;
+    const int64_t blocks = (rows + 3) / 4;
+    LBM_REQUIRE(blocks <= 0x7fffffffLL, LBM_EUNSUPPORTED, "lbm_channel_scale_f32: grid too large");
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, lbm::as_stream(stream), x, y, mean, scale,
+                       rows, C, T);
+    return lbm::check_launch("lbm_channel_scale_f32");
+}

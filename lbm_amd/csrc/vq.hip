@@ -1,0 +1,280 @@
+// VQ-VAE nearest-codebook search (a12/a13): fp32 MFMA distance + fused running argmin.
+//
+// d[n,k] = (|x_n|^2 + |e_k|^2) - 2 x_n.e_k, idx[n] = first k attaining the minimum
+// (training/model.py:90-95, 152-158).  The [N,K] distance matrix never leaves registers.
+//
+// Mapping (v_mfma_f32_32x32x2_f32, exact fp32 fmaf chains):
+//   A operand = codebook tile (rows i = 32 codes), B operand = x^T (columns j = 32 input rows).
+//   A wavefront owns 32 input rows for the whole kernel and keeps them as B fragments in registers
+//   (D/2 VGPRs: lane (j, h) holds x[row j][h*D/2 + s] for MFMA step s), so x is read from HBM once.
+//   The codebook streams through LDS in tiles of 64 codes ([64][D+4] floats: the +4 pad makes the
+//   per-lane ds_read_b128 of 4 consecutive k-steps conflict-free), shared by the 4 waves of the block.
+//   In the 32x32 accumulator a lane holds ONE input row (column j = lane & 31) and 16 codes
+//   ((r&3) + 8*(r>>2) + 4*(lane>>5)), so the running (min, argmin) is a per-lane register update in
+//   ascending code order with strict '<' (first minimum wins); the two lane halves are merged once at
+//   the end with an index tie-break, which reproduces torch.argmin's first-minimum rule exactly.
+#include "common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kThreads = 256;
+constexpr int kTileCodes = 64;
+constexpr int kRowsPerBlock = 128;
+
+template <int DP, int LAYOUT>
+__global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                const float* __restrict__ codebook,
+                                                                const float* __restrict__ e_sqnorm,
+                                                                int64_t* __restrict__ idx_out, float* __restrict__ mind,
+                                                                int64_t N, int D, int K, int vec_ok) {
+    constexpr int HALF = DP / 2;
+    constexpr int LDE = DP + 4;
+    extern __shared__ __align__(16) float smem[];
+    float* s_e = smem;                       // [kTileCodes][LDE]
+    float* s_ee = smem + kTileCodes * LDE;   // [kTileCodes]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave * 32 + j;
+    const int64_t row_c = row < N ? row : N - 1;
+
+    // ---- B fragments: this lane's half of its input row, zero padded to DP
+    float bx[HALF];
+    if constexpr (LAYOUT == LBM_VQ_ROWS) {
+        const float* p = x + row_c * ldx + h * HALF;
+        if (vec_ok && DP == D) {
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) {
+                const float4 v = reinterpret_cast<const float4*>(p)[q];
+                bx[4 * q] = v.x; bx[4 * q + 1] = v.y; bx[4 * q + 2] = v.z; bx[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < HALF; ++s) bx[s] = (h * HALF + s < D) ? p[s] : 0.f;
+        }
+    } else {
+        const int64_t S = ldx;
+        const int64_t b = row_c / S, sp = row_c - b * S;
+        const float* p = x + (b * D + h * HALF) * S + sp;
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) bx[s] = (h * HALF + s < D) ? p[(int64_t)s * S] : 0.f;
+    }
+    float xx = 0.f;
+#pragma unroll
+    for (int s = 0; s < HALF; ++s) xx = fmaf(bx[s], bx[s], xx);
+    xx += __shfl_xor(xx, 32, 64);
+
+    float best = INFINITY;
+    int bidx = 0;
+    const int d4 = D >> 2;  // float4 per codebook row
+    for (int kbase = 0; kbase < K; kbase += kTileCodes) {
+        __syncthreads();  // previous tile fully consumed
+        for (int i = threadIdx.x; i < kTileCodes * (DP / 4); i += kThreads) {
+            const int code = i / (DP / 4), c4 = i - code * (DP / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kbase + code < K && c4 < d4) v = reinterpret_cast<const float4*>(codebook + (int64_t)(kbase + code) * D)[c4];
+            *reinterpret_cast<float4*>(s_e + code * LDE + 4 * c4) = v;
+        }
+        if (threadIdx.x < kTileCodes)
+            s_ee[threadIdx.x] = (kbase + threadIdx.x < K) ? e_sqnorm[kbase + threadIdx.x] : INFINITY;
+        __syncthreads();
+
+#pragma unroll
+        for (int c = 0; c < kTileCodes / 32; ++c) {
+            if (kbase + c * 32 < K) {  // block-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float* ap = s_e + (c * 32 + j) * LDE + h * HALF;
+#pragma unroll
+                for (int q = 0; q < HALF / 4; ++q) {
+                    const float4 a = reinterpret_cast<const float4*>(ap)[q];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bx[4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bx[4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bx[4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bx[4 * q + 3], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float dist = (xx + s_ee[cl]) - 2.f * acc[r];
+                    if (dist < best) {
+                        best = dist;
+                        bidx = kbase + cl;
+                    }
+                }
+            }
+        }
+    }
+    // merge the two lane halves of each input row: smaller distance, then smaller index
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bidx, 32, 64);
+    if (ob < best || (ob == best && oi < bidx)) {
+        best = ob;
+        bidx = oi;
+    }
+    if (h == 0 && row < N) {
+        idx_out[row] = (int64_t)bidx;
+        if (mind != nullptr) mind[row] = best;
+    }
+}
+
+// usage histogram of int64 indices: LDS-privatised bins, one 64-bit atomic per non-empty bin per block
+__global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ idx, unsigned long long* __restrict__ hist,
+                                                   int64_t N, int K) {
+    extern __shared__ unsigned int s_h[];
+    for (int i = threadIdx.x; i < K; i += 256) s_h[i] = 0u;
+    __syncthreads();
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < N; n += (int64_t)gridDim.x * 256) {
+        const int64_t k = idx[n];
+        if (k >= 0 && k < K) atomicAdd(&s_h[(int)k], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 256)
+        if (s_h[i] != 0u) atomicAdd(&hist[i], (unsigned long long)s_h[i]);
+}
+
+__global__ __launch_bounds__(256) void rownorm2_kernel(const float* __restrict__ m, float* __restrict__ out, int64_t rows,
+                                                       int D) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float v = m[row * (int64_t)D + d];
+        s = fmaf(v, v, s);
+    }
+    s = lbm::wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+
+// quantized = x + (E[idx] - x) (straight-through arithmetic), sq_err_sum += sum((E[idx]-x)^2) in float64
+__global__ __launch_bounds__(256) void gather_loss_kernel(const float* __restrict__ x, const float* __restrict__ codebook,
+                                                          const int64_t* __restrict__ idx, float* __restrict__ quantized,
+                                                          double* __restrict__ sq_err_sum, int64_t N, int D, int K) {
+    __shared__ double s_part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double err = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+        int64_t k = idx[row];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+        for (int d = lane; d < D; d += 64) {
+            const float xv = x[row * (int64_t)D + d];
+            const float diff = codebook[k * D + d] - xv;
+            if (quantized != nullptr) quantized[row * (int64_t)D + d] = xv + diff;
+            err = fma((double)diff, (double)diff, err);
+        }
+    }
+    err = lbm::wave_sum(err);
+    if (lane == 0) s_part[wave] = err;
+    __syncthreads();
+    if (threadIdx.x == 0 && sq_err_sum != nullptr) atomicAdd(sq_err_sum, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
+}
+
+__global__ __launch_bounds__(256) void perplexity_kernel(const unsigned long long* __restrict__ hist, float* __restrict__ out,
+                                                         int K) {
+    __shared__ double s_part[4];
+    __shared__ double s_total;
+    double t = 0.0;
+    for (int i = threadIdx.x; i < K; i += 256) t += (double)hist[i];
+    t = lbm::wave_sum(t);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) s_total = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    __syncthreads();
+    const float total = (float)s_total;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < K; i += 256) {
+        const float p = (float)hist[i] / total;            // avg_probs (training/model.py:143)
+        acc += (double)(p * logf(p + 1e-10f));               // fp32 term, float64 accumulation
+    }
+    acc = lbm::wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = expf(-(float)((s_part[0] + s_part[1]) + (s_part[2] + s_part[3])));
+}
+
+template <int DP>
+int launch_vq(const float* x, int64_t ldx, int layout, const float* codebook, const float* e_sqnorm, int64_t* idx_out,
+              float* mind, int64_t N, int D, int K, hipStream_t st) {
+    const size_t lds = ((size_t)kTileCodes * (DP + 4) + kTileCodes) * sizeof(float);
+    const int64_t blocks = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: grid too large");
+    const int vec_ok = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
+    hipError_t e;
+    if (layout == LBM_VQ_ROWS) {
+        auto k = vq_argmin_kernel<DP, LBM_VQ_ROWS>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok);
+    } else {
+        auto k = vq_argmin_kernel<DP, LBM_VQ_CHANNEL_MAJOR>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok);
+    }
+    return lbm::check_launch("lbm_vq_argmin_f32");
+}
+
+}  // namespace
+
+extern "C" int lbm_rownorm2_f32(const float* m, float* out, int64_t rows, int32_t D, lbm_stream_t stream) {
+    LBM_REQUIRE(rows >= 0 && D >= 1, LBM_EINVAL, "lbm_rownorm2_f32: bad sizes");
+    if (rows == 0) return LBM_OK;
+    LBM_REQUIRE(m && out, LBM_EINVAL, "lbm_rownorm2_f32: NULL pointer");
+    const int64_t blocks = (rows + 3) / 4;
+    LBM_REQUIRE(blocks <= 0x7fffffffLL, LBM_EUNSUPPORTED, "lbm_rownorm2_f32: grid too large");
+    hipLaunchKernelGGL(rownorm2_kernel, dim3((unsigned)blocks), dim3(256), 0, lbm::as_stream(stream), m, out, rows, D);
+    return lbm::check_launch("lbm_rownorm2_f32");
+}
+
+extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, const float* codebook,
+                                 const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
+                                 unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream) {
+    LBM_REQUIRE(N >= 0, LBM_EINVAL, "lbm_vq_argmin_f32: negative N");
+    LBM_REQUIRE(D >= 8 && D <= 256 && (D & 7) == 0, LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: D=%d must be a multiple of 8 in [8,256]", D);
+    LBM_REQUIRE(K >= 1, LBM_EINVAL, "lbm_vq_argmin_f32: K must be >= 1");
+    LBM_REQUIRE(layout == LBM_VQ_ROWS || layout == LBM_VQ_CHANNEL_MAJOR, LBM_EINVAL, "lbm_vq_argmin_f32: unknown layout %d", layout);
+    if (N == 0) return LBM_OK;
+    LBM_REQUIRE(x && codebook && e_sqnorm && idx_out, LBM_EINVAL, "lbm_vq_argmin_f32: NULL pointer");
+    LBM_REQUIRE(((uintptr_t)codebook & 15) == 0, LBM_EINVAL, "lbm_vq_argmin_f32: codebook must be 16-byte aligned");
+    if (layout == LBM_VQ_ROWS)
+        LBM_REQUIRE(ldx >= D, LBM_EINVAL, "lbm_vq_argmin_f32: ldx (%lld) < D (%d)", (long long)ldx, D);
+    else
+        LBM_REQUIRE(ldx >= 1 && N % ldx == 0, LBM_EINVAL, "lbm_vq_argmin_f32: channel-major needs N %% S == 0 (N=%lld, S=%lld)", (long long)N, (long long)ldx);
+    hipStream_t st = lbm::as_stream(stream);
+    int rc;
+    if (D <= 64) rc = launch_vq<64>(x, ldx, layout, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else if (D <= 128) rc = launch_vq<128>(x, ldx, layout, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else rc = launch_vq<256>(x, ldx, layout, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    if (rc != LBM_OK) return rc;
+    if (hist_or_null != nullptr) {
+        LBM_REQUIRE(K <= 32768, LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: histogram supports K <= 32768");
+        int64_t blocks = (N + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)blocks), dim3(256), (size_t)K * sizeof(unsigned int), st, idx_out, hist_or_null, N, K);
+        rc = lbm::check_launch("lbm_vq_argmin_f32(hist)");
+    }
+    return rc;
+}
+
+extern "C" int lbm_vq_gather_loss_f32(const float* x, const float* codebook, const int64_t* idx, float* quantized,
+                                      double* sq_err_sum, int64_t N, int32_t D, int32_t K, lbm_stream_t stream) {
+    LBM_REQUIRE(N >= 0 && D >= 1 && K >= 1, LBM_EINVAL, "lbm_vq_gather_loss_f32: bad sizes");
+    if (N == 0) return LBM_OK;
+    LBM_REQUIRE(x && codebook && idx, LBM_EINVAL, "lbm_vq_gather_loss_f32: NULL pointer");
+    int64_t blocks = (N + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gather_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, lbm::as_stream(stream), x, codebook, idx, quantized,
+                       sq_err_sum, N, D, K);
+    return lbm::check_launch("lbm_vq_gather_loss_f32");
+}
+
+extern "C" int lbm_perplexity_u64(const unsigned long long* hist, float* out, int32_t K, lbm_stream_t stream) {
+    LBM_REQUIRE(K >= 1 && hist && out, LBM_EINVAL, "lbm_perplexity_u64: bad arguments");
+    hipLaunchKernelGGL(perplexity_kernel, dim3(1), dim3(256), 0, lbm::as_stream(stream), hist, out, K);
+    return lbm::check_launch("lbm_perplexity_u64");
+}

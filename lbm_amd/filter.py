@@ -1,0 +1,140 @@
+"""Zero-phase FIR filtering: MNE-shaped functional surface over ``lbm_fir_f32``.
+
+Mirrors ``raw.filter(l_freq, h_freq, fir_design='firwin')`` (training/preprocess.py:77,
+multi-train/withpsd.py:118, preprocessing_unsupervised.py:36) and
+``raw.notch_filter(freqs, fir_design='firwin')`` (training/preprocess.py:82, multi-train/withpsd.py:119).
+The filter is designed on the host in float64 (a few hundred taps, once per configuration); the
+application over ``[..., T]`` runs on the GPU.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_LENGTH_FACTORS = {"hamming": 3.3, "hann": 3.1, "blackman": 5.0}
+
+
+def _sym_window(name: str, n: int) -> np.ndarray:
+    if n == 1:
+        return np.ones(1)
+    k = np.arange(n, dtype=np.float64)
+    c1 = np.cos(2.0 * np.pi * k / (n - 1))
+    if name == "hamming":
+        return 0.54 - 0.46 * c1
+    if name == "hann":
+        return 0.5 - 0.5 * c1
+    if name == "blackman":
+        return 0.42 - 0.5 * c1 + 0.08 * np.cos(4.0 * np.pi * k / (n - 1))
+    raise ValueError(f"unsupported fir_window {name!r}")
+
+
+def _lowpass_sinc(numtaps: int, cutoff: float, window: str) -> np.ndarray:
+    """Windowed-sinc low-pass, cutoff normalised to Nyquist, unit DC gain (firwin semantics)."""
+    m = np.arange(numtaps, dtype=np.float64) - 0.5 * (numtaps - 1)
+    h = cutoff * np.sinc(cutoff * m)
+    h *= _sym_window(window, numtaps)
+    return h / h.sum()
+
+
+def _compose(n_taps: int, freq: Sequence[float], gain: Sequence[int], window: str) -> np.ndarray:
+    h = np.zeros(n_taps, dtype=np.float64)
+    if gain[-1] == 1:
+        h[n_taps // 2] = 1.0
+    prev_f, prev_g = freq[-1], gain[-1]
+    for f, g in zip(freq[-2::-1], gain[-2::-1]):
+        if g != prev_g:
+            trans = (prev_f - f) / 2.0
+            n = int(round(_LENGTH_FACTORS[window] / trans))
+            n += 1 - n % 2
+            if n > n_taps:
+                raise ValueError("filter_length is too short for the requested transition band")
+            lp = _lowpass_sinc(n, (prev_f + f) / 2.0, window)
+            off = (n_taps - n) // 2
+            if g == 0:
+                h[off:n_taps - off] -= lp
+            else:
+                h[off:n_taps - off] += lp
+        prev_f, prev_g = f, g
+    return h
+
+
+def create_filter(sfreq: float, l_freq: Optional[float], h_freq: Optional[float],
+                  l_trans_bandwidth="auto", h_trans_bandwidth="auto", fir_window: str = "hamming",
+                  fir_design: str = "firwin", phase: str = "zero") -> np.ndarray:
+    """FIR design with MNE's defaults (float64 taps, odd length, linear phase)."""
+    if fir_design != "firwin" or phase != "zero":
+        raise NotImplementedError("only fir_design='firwin', phase='zero' (the reference's settings)")
+    sfreq = float(sfreq)
+    nyq = sfreq / 2.0
+    l_tr = None if l_freq is None else (min(max(0.25 * l_freq, 2.0), l_freq)
+                                        if isinstance(l_trans_bandwidth, str) else float(l_trans_bandwidth))
+    h_tr = None if h_freq is None else (min(max(0.25 * h_freq, 2.0), nyq - h_freq)
+                                        if isinstance(h_trans_bandwidth, str) else float(h_trans_bandwidth))
+    if l_freq is not None and h_freq is not None and l_freq > h_freq:      # band-stop
+        freq = [0.0, h_freq, h_freq + h_tr, l_freq - l_tr, l_freq, nyq]
+        gain = [1, 1, 0, 0, 1, 1]
+        mt = min(l_tr, h_tr)
+    elif l_freq is not None and h_freq is not None:                        # band-pass
+        freq = [0.0, l_freq - l_tr, l_freq, h_freq, h_freq + h_tr, nyq]
+        gain = [0, 0, 1, 1, 0, 0]
+        if freq[1] <= 0:
+            freq, gain = [0.0] + freq[2:], gain[1:]
+        if freq[-2] >= nyq:
+            freq, gain = freq[:-1], gain[:-1]
+        mt = min(l_tr, h_tr)
+    elif h_freq is not None:                                               # low-pass
+        freq, gain, mt = [0.0, h_freq, h_freq + h_tr, nyq], [1, 1, 0, 0], h_tr
+    elif l_freq is not None:                                               # high-pass
+        freq, gain, mt = [0.0, l_freq - l_tr, l_freq, nyq], [0, 0, 1, 1], l_tr
+    else:
+        raise ValueError("l_freq and h_freq cannot both be None")
+    n_taps = int(round(_LENGTH_FACTORS[fir_window] * sfreq / mt))
+    n_taps += 1 - n_taps % 2
+    fn = [f / nyq for f in freq]
+    fn[-1] = 1.0
+    return _compose(n_taps, fn, gain, fir_window)
+
+
+def fir_apply(data, taps, pad: str = "reflect_limited"):
+    """Apply symmetric odd-length FIR taps along the last axis of a CUDA/array tensor (fp32 on device)."""
+    pad_mode = {"reflect_limited": _lib.PAD_REFLECT_LIMITED, "zero": _lib.PAD_ZERO}[pad]
+    was_numpy = not isinstance(data, torch.Tensor)
+    x = _lib.dev_f32(data)
+    T = x.shape[-1] if x.dim() else 0
+    rows = x.numel() // T if T else 0
+    t = torch.as_tensor(np.asarray(taps, dtype=np.float64), dtype=torch.float64).to(x.device).to(torch.float32) \
+        if not (isinstance(taps, torch.Tensor) and taps.is_cuda) else taps.to(torch.float32).contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().lbm_fir_f32(_lib.ptr(x), _lib.ptr(y), rows, T, _lib.ptr(t), t.numel(), pad_mode,
+                                       _lib.stream_ptr()), "lbm_fir_f32")
+    return y.cpu().numpy().astype(np.float64) if was_numpy else y
+
+
+def filter_data(data, sfreq, l_freq, h_freq, *, l_trans_bandwidth="auto", h_trans_bandwidth="auto",
+                fir_design="firwin", phase="zero", fir_window="hamming", pad="reflect_limited"):
+    """``mne.filter.filter_data`` equivalent (array in, array out) on the GPU."""
+    taps = create_filter(sfreq, l_freq, h_freq, l_trans_bandwidth, h_trans_bandwidth, fir_window, fir_design, phase)
+    return fir_apply(data, taps, pad)
+
+
+def notch_taps(sfreq, freqs, notch_widths=None, trans_bandwidth: float = 1.0, fir_window="hamming"):
+    freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
+    widths = freqs / 200.0 if notch_widths is None else np.broadcast_to(np.asarray(notch_widths, dtype=np.float64), freqs.shape)
+    tb_2 = trans_bandwidth / 2.0
+    return [create_filter(sfreq, f + w / 2.0 + tb_2, f - w / 2.0 - tb_2, tb_2, tb_2, fir_window) for f, w in zip(freqs, widths)]
+
+
+def notch_filter(data, sfreq, freqs, *, notch_widths=None, trans_bandwidth=1.0, fir_design="firwin",
+                 fir_window="hamming", pad="reflect_limited"):
+    """``mne.filter.notch_filter`` equivalent: one band-stop FIR per notch frequency, applied in sequence."""
+    if fir_design != "firwin":
+        raise NotImplementedError("only fir_design='firwin'")
+    was_numpy = not isinstance(data, torch.Tensor)
+    y = _lib.dev_f32(data)
+    for taps in notch_taps(sfreq, freqs, notch_widths, trans_bandwidth, fir_window):
+        y = fir_apply(y, taps, pad)
+    return y.cpu().numpy().astype(np.float64) if was_numpy else y

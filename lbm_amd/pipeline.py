@@ -1,0 +1,175 @@
+"""Fused driver of the batched EEG epoch pipeline on one GPU, plus the multi-GPU shard/gather helpers.
+
+filter (a1) -> ICA affine (a3) -> baseline / peak-to-peak keep mask / z-score (a4-a6) -> Welch PSD on the
+cleaned epochs (a7) -> band powers (a8) -> VQ-VAE encoder (a10) -> codebook argmin + usage histogram (a12).
+Order and parameters follow training/preprocess.py:77-287 and multi-train/withpsd.py:118-270, applied per
+epoch.  All buffers are allocated once per chunk size; a chunk run only enqueues
+kernels on the current stream (no host sync, no allocation).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .constants import ZSCORE_EPSILON
+from .psd import welch_bins, welch_tables
+
+
+@dataclass
+class PipelineConfig:
+    sfreq: float = 500.0
+    n_channels: int = 30
+    n_times: int = 1500
+    n_baseline: int = 251
+    reject: float = 150e-6
+    n_fft: Optional[int] = None        # default int(sfreq)  (multi-train/withpsd.py:231)
+    n_overlap: Optional[int] = None    # default n_fft // 2  (multi-train/withpsd.py:243)
+    window: str = "hann"
+    fmin: float = 4.0
+    fmax: float = 30.0
+    zscore_eps: float = ZSCORE_EPSILON
+    do_tokenize: bool = True
+    do_filter: bool = True
+    do_ica: bool = True
+
+
+class EpochPipeline:
+    def __init__(self, cfg: PipelineConfig, taps, A, b, encoder: Optional[dict], codebook, device=None):
+        self.cfg = cfg
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.lib = _lib.load()
+        f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).to(self.dev, torch.float32).contiguous()  # noqa: E731
+        self.taps = f32(taps) if taps is not None else None
+        self.A = f32(A) if A is not None else None
+        self.b = f32(b) if b is not None else None
+        self.n_fft = int(cfg.sfreq) if cfg.n_fft is None else int(cfg.n_fft)
+        self.n_overlap = self.n_fft // 2 if cfg.n_overlap is None else int(cfg.n_overlap)
+        self.freqs, self.bin_lo, self.bin_hi = welch_bins(cfg.sfreq, self.n_fft, cfg.fmin, cfg.fmax)
+        self.F = self.bin_hi - self.bin_lo + 1
+        self.freqs_dev = torch.as_tensor(self.freqs).to(self.dev, torch.float32)
+        self.tables = welch_tables(self.dev, self.n_fft, self.n_fft, cfg.window, self.bin_lo, self.bin_hi)
+        self.window_id = {"boxcar": _lib.WIN_BOXCAR, "hann": _lib.WIN_HANN, "hamming": _lib.WIN_HAMMING}[cfg.window]
+        self.enc = None
+        if cfg.do_tokenize:
+            self.enc = {k: torch.as_tensor(np.asarray(v)).to(self.dev, torch.float32).contiguous()
+                        for k, v in encoder.items() if k.startswith("encoder.")}
+            self.codebook = torch.as_tensor(np.asarray(codebook)).to(self.dev, torch.float32).contiguous()
+            self.K, self.D = self.codebook.shape
+            self.ee = torch.empty((self.K,), dtype=torch.float32, device=self.dev)
+            _lib.check(self.lib.lbm_rownorm2_f32(_lib.ptr(self.codebook), _lib.ptr(self.ee), self.K, self.D, _lib.stream_ptr()))
+            T = cfg.n_times
+            self.L1 = (T + 2 - 4) // 2 + 1
+            self.L2 = (self.L1 + 2 - 4) // 2 + 1
+            self.S = self.L2
+        self._cap = 0
+        self._buf: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ buffers
+    def _reserve(self, E: int):
+        if E <= self._cap:
+            return
+        c, d = self.cfg, self.dev
+        mk = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=d)  # noqa: E731
+        B = {"filt": mk(E, c.n_channels, c.n_times), "clean": mk(E, c.n_channels, c.n_times),
+             "std": mk(E, c.n_channels, c.n_times), "keep": mk(E, dt=torch.uint8),
+             "psd": mk(E, c.n_channels, self.F), "bp": mk(E, 6)}
+        if c.do_tokenize:
+            B.update(h1=mk(E, 64, self.L1), h2=mk(E, 128, self.L2), h3=mk(E, 256, self.L2), z=mk(E, self.D, self.L2),
+                     tokens=mk(E, self.S, dt=torch.int64), hist=torch.zeros((self.K,), dtype=torch.int64, device=d))
+        self._buf, self._cap = B, E
+
+    def reset_hist(self):
+        if "hist" in self._buf:
+            self._buf["hist"].zero_()
+
+    # ------------------------------------------------------------------ one chunk
+    def run(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """x: [E, C, T] float32 CUDA tensor.  Returns views into the pipeline's buffers (valid until the next run)."""
+        c, lib, p, st = self.cfg, self.lib, _lib.ptr, _lib.stream_ptr()
+        if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+            raise ValueError("x must be a contiguous float32 CUDA tensor")
+        E, C, T = x.shape
+        if (C, T) != (c.n_channels, c.n_times):
+            raise ValueError(f"expected [E, {c.n_channels}, {c.n_times}], got {tuple(x.shape)}")
+        self._reserve(E)
+        B = {k: (v[:E] if k != "hist" else v) for k, v in self._buf.items()}
+        cur = x
+        if c.do_filter:
+            _lib.check(lib.lbm_fir_f32(p(cur), p(B["filt"]), E * C, T, p(self.taps), self.taps.numel(), _lib.PAD_REFLECT_LIMITED, st), "fir")
+            cur = B["filt"]
+        if c.do_ica:
+            _lib.check(lib.lbm_affine_ch_f32(p(cur), p(B["clean"]), E, C, C, T, p(self.A), p(self.b), st), "affine")
+            cur = B["clean"]
+        base = B["clean"]
+        _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base), p(B["std"]) if c.do_tokenize else None, p(B["keep"]), E, C, T,
+                                          c.n_baseline, float(c.reject),
+                                          _lib.STD_EPOCH_CHANNEL if c.do_tokenize else _lib.STD_NONE, c.zscore_eps, st), "post")
+        _lib.check(lib.lbm_welch_f32(p(base), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft, self.n_fft,
+                                     self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, _lib.AVG_MEAN, st), "welch")
+        _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
+        out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"], "cleaned": base}
+        if c.do_tokenize:
+            e = self.enc
+            conv = lambda xi, yo, i, cin, lin, cout, ks, s_, pd, relu: _lib.check(  # noqa: E731
+                lib.lbm_conv1d_f32(p(xi), p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), E, cin, lin, cout, ks, s_, pd, relu, st), "conv")
+            conv(B["std"], B["h1"], 0, C, T, 64, 4, 2, 1, 1)
+            conv(B["h1"], B["h2"], 2, 64, self.L1, 128, 4, 2, 1, 1)
+            conv(B["h2"], B["h3"], 4, 128, self.L2, 256, 3, 1, 1, 1)
+            conv(B["h3"], B["z"], 6, 256, self.L2, self.D, 1, 1, 0, 0)
+            _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.S, _lib.VQ_CHANNEL_MAJOR, p(self.codebook), p(self.ee),
+                                             p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
+            out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"])
+        return out
+
+
+# ---------------------------------------------------------------------- multi-GPU helpers (one process per GPU)
+def shard_range(E: int, rank: int, world: int):
+    """Contiguous block of epochs owned by `rank`; concatenating shards in rank order reproduces
+    np.concatenate order (training/model.py:423)."""
+    base, rem = divmod(E, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_epoch_outputs(local: torch.Tensor, group=None) -> torch.Tensor:
+    """all_gather of a per-epoch array [E_local, ...] whose E_local may differ between ranks.
+    Equal shards use one all_gather_into_tensor; unequal shards gather counts first, then padded blocks."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    local = local.contiguous()
+    if min(counts) == mx:
+        out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        return out
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    blocks = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(blocks, pad, group=group)
+    return torch.cat([blk[:c] for blk, c in zip(blocks, counts)], dim=0)
+
+
+def allreduce_hist(hist: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of the K-entry codebook usage histogram over ranks (the only reduction of the path)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    return hist
+
+
+def perplexity_from_counts(hist: torch.Tensor) -> float:
+    """Host-side perplexity of a (globally reduced) histogram, exp(-sum p log(p+1e-10)) in fp32 like
+    training/model.py:143-144.  Device tensors should use quantizer.perplexity_from_hist instead."""
+    h = hist.detach().to("cpu", torch.float32)
+    pr = h / h.sum()
+    return float(torch.exp(-torch.sum(pr * torch.log(pr + 1e-10))))

@@ -1,0 +1,227 @@
+"""VQ-VAE tokenizer: drop-in for the quantizer part of the reference's training/model.py.
+
+Same class names, constructor arguments, parameter/buffer names (so ``training/vq_vae_model.pth`` loads
+unchanged) and return values as ``VectorQuantizerEMA`` (training/model.py:66-158), ``VQVAE`` (:162-214)
+and ``encode_data_for_transformer`` (:411-427); the arithmetic on the encode path runs in
+liblbm_hip.so (fp32 MFMA conv + fp32 MFMA distance/argmin), never on a CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .constants import VQ_EMBEDDING_DIM
+
+
+# ------------------------------------------------------------------------------------------ functional layer
+def rownorm2(m: torch.Tensor) -> torch.Tensor:
+    m = _lib.dev_f32(m)
+    out = torch.empty((m.shape[0],), dtype=torch.float32, device=m.device)
+    _lib.check(_lib.load().lbm_rownorm2_f32(_lib.ptr(m), _lib.ptr(out), m.shape[0], m.shape[1], _lib.stream_ptr()),
+               "lbm_rownorm2_f32")
+    return out
+
+
+def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = None, *, channel_major: bool = False,
+              return_min: bool = False, hist: torch.Tensor = None):
+    """Nearest-code indices (int64).
+
+    x: [N, D] rows (any row stride that is a multiple of 1 float), or with ``channel_major`` the encoder
+    output z[B, D, S] (N = B*S rows, no permute/contiguous copy).  ``hist`` ([K] int64/uint64 counts) is
+    ADDED to when given.
+    """
+    if not x.is_cuda or x.dtype != torch.float32:
+        x = _lib.dev_f32(x)
+    cb = _lib.dev_f32(codebook)
+    K, D = cb.shape
+    if e_sqnorm is None:
+        e_sqnorm = rownorm2(cb)
+    if channel_major:
+        x = x.contiguous()
+        B, Dx, S = x.shape
+        N, ldx, layout = B * S, S, _lib.VQ_CHANNEL_MAJOR
+    else:
+        if x.dim() != 2:
+            raise ValueError("x must be [N, D]")
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        N, Dx = x.shape
+        ldx, layout = (x.stride(0) if N > 1 else Dx), _lib.VQ_ROWS
+    if Dx != D:
+        raise ValueError(f"input dim {Dx} != codebook dim {D}")
+    idx = torch.empty((N,), dtype=torch.int64, device=x.device)
+    mind = torch.empty((N,), dtype=torch.float32, device=x.device) if return_min else None
+    if hist is not None and (hist.dtype != torch.int64 or hist.numel() != K or not hist.is_contiguous()):
+        raise ValueError("hist must be a contiguous int64 tensor of K entries")
+    _lib.check(_lib.load().lbm_vq_argmin_f32(_lib.ptr(x), ldx, layout, _lib.ptr(cb), _lib.ptr(e_sqnorm), _lib.ptr(idx),
+                                             _lib.ptr(mind), _lib.ptr(hist), N, D, K, _lib.stream_ptr()), "lbm_vq_argmin_f32")
+    return (idx, mind) if return_min else idx
+
+
+def vq_gather_loss(x: torch.Tensor, codebook: torch.Tensor, idx: torch.Tensor, want_quantized: bool = True):
+    """(quantized with straight-through arithmetic [N, D] or None, sum of squared error as a float64 scalar tensor)."""
+    x = _lib.dev_f32(x)
+    cb = _lib.dev_f32(codebook)
+    N, D = x.shape
+    q = torch.empty_like(x) if want_quantized else None
+    err = torch.zeros((1,), dtype=torch.float64, device=x.device)
+    _lib.check(_lib.load().lbm_vq_gather_loss_f32(_lib.ptr(x), _lib.ptr(cb), _lib.ptr(idx), _lib.ptr(q), _lib.ptr(err), N, D,
+                                                  cb.shape[0], _lib.stream_ptr()), "lbm_vq_gather_loss_f32")
+    return q, err
+
+
+def perplexity_from_hist(hist: torch.Tensor) -> torch.Tensor:
+    """exp(-sum p log(p + 1e-10)), p = hist / sum(hist)  (training/model.py:142-144)."""
+    out = torch.empty((1,), dtype=torch.float32, device=hist.device)
+    _lib.check(_lib.load().lbm_perplexity_u64(_lib.ptr(hist), _lib.ptr(out), hist.numel(), _lib.stream_ptr()),
+               "lbm_perplexity_u64")
+    return out[0]
+
+
+def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, stride: int = 1, padding: int = 0,
+           relu: bool = False) -> torch.Tensor:
+    """nn.Conv1d (+ReLU) forward on fp32 MFMA.  x: [B, Cin, L]; weight: [Cout, Cin, k]."""
+    x = _lib.dev_f32(x)
+    w = _lib.dev_f32(weight)
+    b = _lib.dev_f32(bias) if bias is not None else None
+    B, Cin, Lin = x.shape
+    Cout, Cin_w, ks = w.shape
+    if Cin_w != Cin:
+        raise ValueError(f"weight expects {Cin_w} input channels, got {Cin}")
+    Lout = (Lin + 2 * padding - ks) // stride + 1
+    y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().lbm_conv1d_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, Lin, Cout, ks, stride,
+                                          padding, int(relu), _lib.stream_ptr()), "lbm_conv1d_f32")
+    return y
+
+
+def encoder_forward(x: torch.Tensor, enc: "nn.Sequential | dict") -> torch.Tensor:
+    """VQVAE.encoder (training/model.py:169-177) on the HIP conv kernel: [B, C, L] -> [B, D, L//4]."""
+    if isinstance(enc, dict):
+        g = lambda i, n: enc[f"encoder.{i}.{n}"]  # noqa: E731
+    else:
+        g = lambda i, n: getattr(enc[i], n)  # noqa: E731
+    z = conv1d(x, g(0, "weight"), g(0, "bias"), 2, 1, True)
+    z = conv1d(z, g(2, "weight"), g(2, "bias"), 2, 1, True)
+    z = conv1d(z, g(4, "weight"), g(4, "bias"), 1, 1, True)
+    return conv1d(z, g(6, "weight"), g(6, "bias"), 1, 0, False)
+
+
+# ------------------------------------------------------------------------------------------ modules
+class VectorQuantizerEMA(nn.Module):
+    def __init__(self, num_embeddings, embedding_dim, commitment_cost, decay, epsilon=1e-5):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.num_embeddings = num_embeddings
+        self.commitment_cost = commitment_cost
+        self.decay = decay
+        self.epsilon = epsilon
+        self.embedding = nn.Embedding(self.num_embeddings, self.embedding_dim)
+        self.embedding.weight.data.uniform_(-1. / self.num_embeddings, 1. / self.num_embeddings)
+        self.register_buffer('ema_cluster_size', torch.zeros(num_embeddings))
+        self.register_buffer('ema_w', torch.zeros_like(self.embedding.weight.data))
+        self._ee_key = None
+        self._ee = None
+
+    def _e_sqnorm(self) -> torch.Tensor:
+        w = self.embedding.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if self._ee_key != key:
+            self._ee = rownorm2(w.detach())
+            self._ee_key = key
+        return self._ee
+
+    def get_code_indices(self, flat_input):
+        return vq_argmin(flat_input.detach(), self.embedding.weight.detach(), self._e_sqnorm())
+
+    def get_code_indices_channel_major(self, z, hist=None):
+        """Indices for an encoder output z[B, D, S] without the permute/contiguous copy."""
+        return vq_argmin(z.detach(), self.embedding.weight.detach(), self._e_sqnorm(), channel_major=True, hist=hist)
+
+    def forward(self, inputs):
+        input_shape = inputs.shape
+        flat_input = inputs.reshape(-1, self.embedding_dim)
+        w = self.embedding.weight
+        K = self.num_embeddings
+        hist = torch.zeros((K,), dtype=torch.int64, device=flat_input.device)
+        idx = vq_argmin(flat_input.detach(), w.detach(), self._e_sqnorm(), hist=hist)
+
+        grad_path = torch.is_grad_enabled() and (inputs.requires_grad or w.requires_grad)
+        if self.training or grad_path:
+            # differentiable gather with the PRE-update codebook (training/model.py:100)
+            quantized = F.embedding(idx, w).view(input_shape)
+        if self.training:
+            # EMA codebook update (training/model.py:103-126); segmented sums instead of one-hot matmuls
+            with torch.no_grad():
+                counts = hist.to(torch.float32)
+                self.ema_cluster_size = self.ema_cluster_size * self.decay + (1 - self.decay) * counts
+                n = torch.sum(self.ema_cluster_size)
+                self.ema_cluster_size = ((self.ema_cluster_size + self.epsilon) / (n + K * self.epsilon) * n)
+                dw = torch.zeros_like(self.ema_w).index_add_(0, idx, flat_input.detach())
+                self.ema_w = self.ema_w * self.decay + (1 - self.decay) * dw
+                self.embedding.weight.data.copy_(self.ema_w / self.ema_cluster_size.unsqueeze(1))
+        if self.training or grad_path:
+            e_latent_loss = F.mse_loss(quantized.detach(), inputs)
+            q_latent_loss = F.mse_loss(quantized, inputs.detach())
+            loss = q_latent_loss + self.commitment_cost * e_latent_loss
+            quantized = inputs + (quantized - inputs).detach()
+        else:
+            q, err = vq_gather_loss(flat_input.detach(), w.detach(), idx)
+            mse = (err[0] / flat_input.numel()).to(torch.float32)
+            loss = mse + self.commitment_cost * mse
+            quantized = q.view(input_shape)
+        perplexity = perplexity_from_hist(hist)
+        return loss, quantized, perplexity, idx.view(input_shape[0], -1)
+
+
+class VQVAE(nn.Module):
+    def __init__(self, input_channels, embedding_dim, num_embeddings, commitment_cost, decay):
+        super().__init__()
+        self.input_channels = input_channels
+        self.embedding_dim = embedding_dim
+        self.encoder = nn.Sequential(
+            nn.Conv1d(input_channels, 64, kernel_size=4, stride=2, padding=1), nn.ReLU(),
+            nn.Conv1d(64, 128, kernel_size=4, stride=2, padding=1), nn.ReLU(),
+            nn.Conv1d(128, 256, kernel_size=3, stride=1, padding=1), nn.ReLU(),
+            nn.Conv1d(256, embedding_dim, kernel_size=1, stride=1))
+        self.vq_layer = VectorQuantizerEMA(num_embeddings, embedding_dim, commitment_cost, decay)
+        self.decoder = nn.Sequential(
+            nn.ConvTranspose1d(embedding_dim, 256, kernel_size=1, stride=1), nn.ReLU(),
+            nn.ConvTranspose1d(256, 128, kernel_size=3, stride=1, padding=1), nn.ReLU(),
+            nn.ConvTranspose1d(128, 64, kernel_size=4, stride=2, padding=1, output_padding=1), nn.ReLU(),
+            nn.ConvTranspose1d(64, input_channels, kernel_size=4, stride=2, padding=1, output_padding=1))
+
+    def forward(self, x):
+        """Training/eval forward with reconstruction (training/model.py:195-203).  The encoder/decoder run
+        through torch autograd here (training is outside the hot path); the quantizer uses the HIP kernels."""
+        z = self.encoder(x)
+        z_permuted = z.permute(0, 2, 1).contiguous()
+        vq_loss, quantized, perplexity, indices = self.vq_layer(z_permuted)
+        x_recon = self.decoder(quantized.permute(0, 2, 1).contiguous())
+        return vq_loss, x_recon, perplexity, indices
+
+    @torch.no_grad()
+    def encode(self, x, hist=None):
+        """Input x[B, C, L] -> code indices int64 [B, L//4] (training/model.py:206-214), all on HIP kernels;
+        the encoder output is consumed channel-major, so the permute(0,2,1).contiguous() copy disappears."""
+        z = encoder_forward(x, self.encoder)
+        idx = self.vq_layer.get_code_indices_channel_major(z, hist=hist)
+        return idx.view(x.shape[0], -1)
+
+
+def encode_data_for_transformer(vq_model, dataloader, device):
+    """training/model.py:411-427: returns (np.int64 [E, S] indices, np labels).  Batches are encoded
+    back-to-back on the device; indices come back to the host once, after the loop."""
+    vq_model.eval()
+    all_indices, all_labels = [], []
+    with torch.no_grad():
+        for data, labels in dataloader:
+            data = data.to(device, non_blocking=True)
+            all_indices.append(vq_model.encode(data))
+            all_labels.append(labels.numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels))
+    all_indices = torch.cat(all_indices, dim=0).cpu().numpy()
+    all_labels = np.concatenate(all_labels, axis=0)
+    return all_indices, all_labels

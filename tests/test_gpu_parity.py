@@ -1,0 +1,364 @@
+"""GPU parity tests (run with -m gpu on an MI355X): HIP kernels through the C ABI vs the CPU oracle.
+
+Tolerances.  Integer / index outputs: bit-exact, except VQ indices where SURVEY.md 8(a)'s near-tie rule
+applies (and exact duplicate codes must resolve to the lowest index).  Floating point (north_star:
+"within rtol 1e-5 (fp32)"): the oracle computes in float64; FIR/affine/post outputs are compared with
+atol = 1e-5 * rms(row) (per-sample relative error is unbounded at zero crossings), PSD with rtol 1e-5
+plus atol = 1e-5 * max bin of the row.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lbm_amd
+from lbm_amd import _lib
+from lbm_amd.synth import synth_codebook, synth_encoder, synth_epochs, synth_ica
+from oracle import eeg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _lib.load()
+
+
+def _rms_ok(got, want, tol=1e-5):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    rms = np.sqrt((want ** 2).mean(axis=-1, keepdims=True)) + 1e-300
+    err = np.abs(got - want) / rms
+    return float(err.max())
+
+
+# ------------------------------------------------------------------------------------------------ a1 / a2 FIR
+@pytest.mark.parametrize("T", [1500, 1001, 300, 37, 1, 4100])
+def test_fir_bandpass_matches_oracle(T):
+    x = synth_epochs(3, 5, T, seed=1).numpy() if T > 8 else np.random.RandomState(0).randn(3, 5, T).astype(np.float32)
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    y = lbm_amd.fir_apply(torch.from_numpy(x).to(DEV), taps).cpu().numpy()
+    want = orc.fir_zero_phase(x.astype(np.float64), taps)
+    scale = np.sqrt((x.astype(np.float64) ** 2).mean()) + 1e-300
+    # short rows are dominated by the padding transient: compare against the input scale there
+    err = _rms_ok(y, want) if T >= 1001 else float(np.abs(y - want).max() / scale)
+    assert err <= 1e-5, err
+
+
+def test_fir_notch_and_zero_pad_and_via_filter_data():
+    x = synth_epochs(2, 4, 1500, seed=2)
+    y = lbm_amd.notch_filter(x.to(DEV), 500.0, 60.0).cpu().numpy()
+    want = orc.notch_filter(x.numpy().astype(np.float64), 500.0, 60.0)
+    assert _rms_ok(y, want) <= 1e-5
+    # numpy in -> float64 numpy out (drop-in for the scripts' arrays)
+    yn = lbm_amd.filter_data(x.numpy(), 500.0, 4.0, 30.0)
+    assert isinstance(yn, np.ndarray) and yn.dtype == np.float64
+    assert _rms_ok(yn, orc.filter_data(x.numpy().astype(np.float64), 500.0, 4.0, 30.0)) <= 1e-5
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    yz = lbm_amd.fir_apply(x.to(DEV), taps, pad="zero").cpu().numpy()
+    xz = np.pad(x.numpy().astype(np.float64), [(0, 0), (0, 0), (412, 412)])
+    wz = np.stack([[np.convolve(r, taps, mode="valid") for r in e] for e in xz])
+    assert _rms_ok(yz, wz) <= 1e-5
+    # empty input
+    assert lbm_amd.fir_apply(torch.empty(0, 30, 1500, device=DEV), taps).shape == (0, 30, 1500)
+
+
+def test_fir_linearity_at_full_size():
+    """Size-independent property on a BASELINE-size chunk: FIR(a*x1 + x2) == a*FIR(x1) + FIR(x2)."""
+    E = 2048
+    x1 = synth_epochs(E, 30, 1500, seed=3, device=DEV)
+    x2 = synth_epochs(E, 30, 1500, seed=4, device=DEV)
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    y1, y2 = lbm_amd.fir_apply(x1, taps), lbm_amd.fir_apply(x2, taps)
+    y12 = lbm_amd.fir_apply(2.0 * x1 + x2, taps)
+    err = (y12 - (2.0 * y1 + y2)).abs().max() / y12.pow(2).mean().sqrt()
+    assert float(err) < 2e-5
+    # and a sample of rows against the oracle
+    rows = [(0, 0), (1023, 17), (2047, 29)]
+    for e, c in rows:
+        want = orc.fir_zero_phase(x1[e, c].cpu().numpy().astype(np.float64), taps)
+        assert _rms_ok(y1[e, c].cpu().numpy(), want) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ a3 ICA
+@pytest.mark.parametrize("C,T", [(30, 1500), (30, 1001), (64, 1000), (5, 7)])
+def test_ica_apply_matches_oracle(C, T):
+    x = synth_epochs(3, C, T, seed=5).numpy() if T > 8 else np.random.RandomState(1).randn(3, C, T).astype(np.float32) * 1e-5
+    kw = synth_ica(C, exclude=(0, 3))
+    y = lbm_amd.ica_apply(torch.from_numpy(x).to(DEV), **kw).cpu().numpy()
+    want = orc.ica_apply(x.astype(np.float64), **kw)
+    assert _rms_ok(y, want) <= 1e-5
+    # rectangular map: sources of a 20-component decomposition
+    rs = np.random.RandomState(2)
+    ncomp = min(20, C)
+    un = rs.randn(ncomp, ncomp)
+    pca = np.linalg.qr(rs.randn(C, C))[0]
+    s = lbm_amd.ica_get_sources(torch.from_numpy(x).to(DEV), unmixing=un, pca_components=pca, pca_mean=rs.randn(C) * 0.01,
+                                pre_whitener=1e-5, n_components=ncomp).cpu().numpy()
+    rs = np.random.RandomState(2); un = rs.randn(ncomp, ncomp); pca = np.linalg.qr(rs.randn(C, C))[0]; mu = rs.randn(C) * 0.01
+    assert s.shape == (3, ncomp, T)
+    assert _rms_ok(s, orc.ica_sources(x.astype(np.float64), un, pca, mu, 1e-5, ncomp)) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ a4-a6 post
+@pytest.mark.parametrize("T,nb", [(1001, 251), (1500, 251), (10000, 501), (64, 0), (3000, 100)])
+def test_epoch_post_matches_oracle(T, nb):
+    x = synth_epochs(6, 7, T, seed=6) * 3.0 + 2e-5
+    x[2, 3, T // 2] += 400e-6        # a clear artefact: epoch 2 must be rejected
+    xd = x.to(DEV)
+    base, std, keep = lbm_amd.epoch_post(xd, n_baseline=nb, reject=150e-6, standardize=True)
+    x64 = x.numpy().astype(np.float64)
+    wb = orc.baseline_correct(x64, nb)
+    assert _rms_ok(base.cpu().numpy(), wb) <= 1e-5
+    ptp = x64.max(-1) - x64.min(-1)
+    assert not np.any(np.abs(ptp - 150e-6) < 1e-9)   # no epoch sits on the threshold
+    assert np.array_equal(keep.cpu().numpy(), orc.ptp_keep_mask(wb, 150e-6))
+    assert not keep[2]
+    assert float(np.abs(std.cpu().numpy() - orc.zscore_epoch_channel(wb)).max()) <= 2e-5   # unit-variance output
+    z2 = lbm_amd.standardize_epochs(xd).cpu().numpy()
+    assert float(np.abs(z2 - orc.zscore_epoch_channel(x64)).max()) <= 2e-5
+
+
+def test_scaler_matches_oracle():
+    x = synth_epochs(9, 6, 1001, seed=7) + 1e-5
+    sc = lbm_amd.Scaler(scalings="mean")
+    y = sc.fit_transform(x.to(DEV)).cpu().numpy()
+    assert float(np.abs(y - orc.scaler_mean(x.numpy().astype(np.float64))).max()) <= 2e-5
+    mom = sc.moments_.cpu().numpy()
+    x64 = x.numpy().astype(np.float64)
+    np.testing.assert_allclose(mom[:, 0], x64.sum(axis=(0, 2)), rtol=1e-12)
+    np.testing.assert_allclose(mom[:, 1], (x64 ** 2).sum(axis=(0, 2)), rtol=1e-12)
+    assert (mom[:, 2] == 9 * 1001).all()
+
+
+# ------------------------------------------------------------------------------------------------ a7 Welch
+def _psd_err(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    tol = 1e-5 * np.abs(want) + 1e-5 * np.abs(want).max(axis=-1, keepdims=True)
+    return float((np.abs(got - want) / tol).max())
+
+
+@pytest.mark.parametrize("T,fs,nfft,nov,win,fmin,fmax", [
+    (1500, 500.0, 500, 250, "hann", 4.0, 30.0),       # config S (multi-train/withpsd.py:236-246)
+    (1001, 500.0, 500, 250, "hann", 4.0, 30.0),       # config R
+    (10000, 1000.0, 1000, 500, "hann", 4.0, 30.0),    # config L
+    (2048, 250.0, 512, 0, "hamming", 4.0, 30.0),      # preprocessing_unsupervised.py:43 defaults
+    (1001, 500.0, 512, 0, "hamming", 1.0, 40.0),      # multi-train/CLEAN.py:175
+    (700, 100.0, 101, 30, "hann", 0.0, 50.0),         # odd nfft, DC and last bin included
+    (600, 100.0, 100, 50, "boxcar", 0.0, 50.0),       # even nfft incl. Nyquist
+])
+def test_welch_matches_oracle(T, fs, nfft, nov, win, fmin, fmax):
+    x = synth_epochs(2, 5, T, sfreq=fs, seed=8) + 3e-5    # DC offset exercises the per-segment mean removal
+    psd, freqs = lbm_amd.psd_array_welch(x.to(DEV), fs, fmin, fmax, n_fft=nfft, n_overlap=nov, window=win)
+    want, wf = orc.welch_psd(x.numpy().astype(np.float64), fs, fmin, fmax, n_fft=nfft, n_overlap=nov, window=win)
+    assert np.array_equal(freqs, wf) and psd.shape == want.shape
+    assert _psd_err(psd.cpu().numpy(), want) <= 1.0
+
+
+def test_welch_average_modes_and_errors():
+    x = synth_epochs(2, 3, 1500, seed=9)
+    xd = x.to(DEV)
+    x64 = x.numpy().astype(np.float64)
+    for avg in ("median", None):
+        got, _ = lbm_amd.psd_array_welch(xd, 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann", average=avg)
+        want, _ = orc.welch_psd(x64, 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann", average=avg)
+        assert got.shape == want.shape
+        assert _psd_err(got.cpu().numpy().reshape(2, 3, -1), want.reshape(2, 3, -1)) <= 1.0
+    with pytest.warns(UserWarning):   # multi-train/withpsd.py:244 passes average=False
+        got, _ = lbm_amd.psd_array_welch(xd, 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann", average=False)
+    assert got.shape == (2, 3, 27)
+    with pytest.raises(ValueError):
+        lbm_amd.psd_array_welch(xd[..., :100], 500.0, n_fft=500)
+    # n_per_seg < n_fft (zero padded segments)
+    got, _ = lbm_amd.psd_array_welch(xd, 500.0, 4.0, 30.0, n_fft=500, n_per_seg=400, n_overlap=100, window="hann")
+    want, _ = orc.welch_psd(x64, 500.0, 4.0, 30.0, n_fft=500, n_per_seg=400, n_overlap=100, window="hann")
+    assert _psd_err(got.cpu().numpy(), want) <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------ a8 / a9
+def test_bandpower_known_answer_labels(golden_dir):
+    with np.load(os.path.join(golden_dir, "bandpower_kat.npz")) as f:
+        X, y, yv, freqs = f["log_psd"], f["labels"], f["labels_variant"], f["freqs"]
+    bp = lbm_amd.band_powers(torch.from_numpy(X).to(DEV), freqs, already_db=True).cpu().numpy().astype(np.float64)
+    want = np.stack(orc.band_powers(X, freqs, already_db=True), axis=-1)
+    np.testing.assert_allclose(bp, want, rtol=2e-7)
+    thr = float(np.median(bp[:, 5]))
+    lab = np.array([lbm_amd.classify_eeg_state(t, a, b, thr) for t, a, b in bp[:, :3]])
+    assert np.array_equal(lab, y)                                  # 62/62 (preprocessing_unsupervised.py rule)
+    labv = np.array([lbm_amd.classify_eeg_state_variant(t, a, b) for t, a, b in bp[:, :3]])
+    assert np.array_equal(labv, yv)                                # 62/62 (failed/label.py rule)
+    # linear PSD in -> same numbers through the 10*log10 path; per-channel variant
+    lin = 10.0 ** (X / 10.0)
+    bp2 = lbm_amd.band_powers(torch.from_numpy(lin).to(DEV), freqs).cpu().numpy()
+    np.testing.assert_allclose(bp2, want, rtol=1e-5)
+    bpc = lbm_amd.band_powers(torch.from_numpy(lin[:4]).to(DEV), freqs, per_channel=True).cpu().numpy()
+    wantc = np.stack(orc.band_powers(lin[:4, :, None, :], freqs), axis=-1)
+    np.testing.assert_allclose(bpc, wantc, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ a10 encoder
+def test_conv_encoder_matches_reference_golden(shipped, vq_golden):
+    for name in ("S", "R", "P"):
+        x = torch.from_numpy(vq_golden[f"x_{name}"]).to(DEV)
+        z = lbm_amd.encoder_forward(x, {k: torch.from_numpy(v).to(DEV) for k, v in shipped.items()})
+        ref = vq_golden[f"z_{name}"]
+        assert z.shape == ref.shape
+        assert float(np.abs(z.cpu().numpy() - ref).max()) <= 1e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 30, 1500, 64, 4, 2, 1), (2, 64, 101, 128, 4, 2, 1), (2, 7, 33, 70, 3, 1, 1),
+                                                (1, 256, 40, 256, 1, 1, 0), (2, 3, 10, 5, 5, 3, 2)])
+def test_conv1d_matches_torch_cpu(B, Cin, L, Cout, k, s, p):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    for relu in (False, True):
+        y = lbm_amd.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), s, p, relu).cpu()
+        want = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=s, padding=p)
+        want = torch.relu(want) if relu else want
+        assert y.shape == want.shape
+        assert float((y.double() - want).abs().max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ a12-a14 VQ
+def test_vq_golden_get_code_indices(shipped, vq_golden):
+    cb = shipped["vq_layer.embedding.weight"]
+    idx = lbm_amd.vq_argmin(torch.from_numpy(vq_golden["gci_in"]).to(DEV), torch.from_numpy(cb).to(DEV)).cpu().numpy()
+    assert idx.dtype == np.int64
+    ok = orc.vq_near_tie_ok(vq_golden["gci_in"], cb, idx, vq_golden["gci_idx"])
+    assert ok.all()
+    assert (idx[:8] == 406).all()                      # exact ties among the 100 all-zero codes: lowest index
+    assert (idx[8:16] == vq_golden["gci_idx"][8:16]).all()
+    assert (idx == vq_golden["gci_idx"]).mean() >= 0.97
+
+
+def test_vq_duplicate_codes_lowest_index_wins():
+    rs = np.random.RandomState(3)
+    cb = rs.randn(200, 256).astype(np.float32)
+    cb[150] = cb[20]; cb[199] = cb[20]; cb[64] = cb[63]      # duplicates across lane halves, tiles and sub-tiles
+    x = cb[[20, 63, 150, 199, 64, 5]] + 0.0
+    idx = lbm_amd.vq_argmin(torch.from_numpy(x).to(DEV), torch.from_numpy(cb).to(DEV)).cpu().numpy()
+    assert idx.tolist() == [20, 63, 20, 20, 63, 5]
+
+
+@pytest.mark.parametrize("N,D,K", [(1000, 256, 512), (129, 256, 8192), (77, 64, 100), (300, 128, 65), (5, 72, 7), (128, 256, 1)])
+def test_vq_random_codebooks_match_oracle(N, D, K):
+    rs = np.random.RandomState(N + K)
+    cb = rs.randn(K, D).astype(np.float32)
+    x = (cb[rs.randint(0, K, N)] + 0.7 * rs.randn(N, D)).astype(np.float32)
+    hist = torch.zeros(K, dtype=torch.int64, device=DEV)
+    idx, mind = lbm_amd.vq_argmin(torch.from_numpy(x).to(DEV), torch.from_numpy(cb).to(DEV), return_min=True, hist=hist)
+    idx = idx.cpu().numpy()
+    ref = orc.vq_argmin(x, cb)
+    assert orc.vq_near_tie_ok(x, cb, idx, ref).all()
+    assert (idx == ref).mean() >= 0.99
+    d64 = orc.vq_distances_f64(x, cb)
+    np.testing.assert_allclose(mind.cpu().numpy(), d64[np.arange(N), idx], rtol=1e-4, atol=1e-3)
+    assert np.array_equal(hist.cpu().numpy(), np.bincount(idx, minlength=K))
+    # strided rows (ldx > D) and channel-major layout give the same indices
+    wide = torch.zeros(N, D + 8, device=DEV); wide[:, :D] = torch.from_numpy(x).to(DEV)
+    assert np.array_equal(lbm_amd.vq_argmin(wide[:, :D], torch.from_numpy(cb).to(DEV)).cpu().numpy(), idx)
+    if N % 5 == 0:
+        S = N // 5
+        z = torch.from_numpy(x).to(DEV).view(5, S, D).permute(0, 2, 1).contiguous()   # [B, D, S]
+        assert np.array_equal(lbm_amd.vq_argmin(z, torch.from_numpy(cb).to(DEV), channel_major=True).cpu().numpy(), idx)
+
+
+def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
+    m = m.to(DEV).eval()
+    cb = shipped["vq_layer.embedding.weight"]
+    for name in ("S", "R", "P"):
+        x = torch.from_numpy(vq_golden[f"x_{name}"]).to(DEV)
+        tok = m.encode(x).cpu().numpy()
+        ref = vq_golden[f"tokens_{name}"]
+        assert tok.shape == ref.shape and tok.dtype == np.int64
+        z = lbm_amd.encoder_forward(x, m.encoder).permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+        # same-input near-tie rule (the encoder output differs from the CPU one by fp32 rounding)
+        assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
+        assert (tok == ref).mean() >= 0.97
+    # VectorQuantizerEMA.forward in eval mode (training/model.py:84-149)
+    with torch.no_grad():
+        loss, quant, perp, idx = m.vq_layer(torch.from_numpy(vq_golden["vqfwd_in"]).to(DEV))
+    assert orc.vq_near_tie_ok(vq_golden["vqfwd_in"].reshape(-1, 256), cb, idx.cpu().numpy().reshape(-1),
+                              vq_golden["vqfwd_indices"].reshape(-1)).all()
+    same = idx.cpu().numpy() == vq_golden["vqfwd_indices"]
+    assert same.mean() >= 0.97
+    if same.all():
+        np.testing.assert_allclose(quant.cpu().numpy(), vq_golden["vqfwd_quantized"], rtol=0, atol=0)
+        np.testing.assert_allclose(float(loss), vq_golden["vqfwd_loss"], rtol=1e-5)
+        np.testing.assert_allclose(float(perp), vq_golden["vqfwd_perplexity"], rtol=1e-5)
+    # get_code_indices keeps the reference signature: flat [N, D] in, int64 [N] out
+    gi = m.vq_layer.get_code_indices(torch.from_numpy(vq_golden["gci_in"]).to(DEV))
+    assert gi.shape == (1024,) and gi.dtype == torch.int64
+
+
+def test_encode_data_for_transformer_signature(shipped):
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
+    m = m.to(DEV)
+    data = torch.randn(150, 30, 39, generator=torch.Generator().manual_seed(1))
+    labels = torch.arange(150) % 3
+    dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, labels), batch_size=lbm_amd.BATCH_SIZE)
+    idx, lab = lbm_amd.encode_data_for_transformer(m, dl, torch.device(DEV))
+    assert idx.shape == (150, 9) and idx.dtype == np.int64 and np.array_equal(lab, labels.numpy())
+    ref, _ = orc.vqvae_encode(data.numpy(), shipped)
+    assert (idx == ref).mean() >= 0.97
+
+
+# ------------------------------------------------------------------------------------------------ whole pipeline
+def _make_pipeline(shipped, T=1500, C=30, fs=500.0, nb=251):
+    taps = lbm_amd.create_filter(fs, 4.0, 30.0)
+    kw = synth_ica(C)
+    A, b = lbm_amd.ica_projection(**kw)
+    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb)
+    return lbm_amd.EpochPipeline(cfg, taps, A, b, shipped, shipped["vq_layer.embedding.weight"]), taps, A, b
+
+
+@pytest.mark.parametrize("T", [1500, 1001])
+def test_pipeline_matches_oracle(shipped, T):
+    pipe, taps, A, b = _make_pipeline(shipped, T=T)
+    x = synth_epochs(6, 30, T, seed=10) * 2.0
+    x[4, 7, 700] += 1e-2       # artefact -> epoch 4 rejected
+    out = pipe.run(x.to(DEV))
+    torch.cuda.synchronize()
+    want = orc.pipeline(x.numpy(), 500.0, taps, A, b, 251, 150e-6, shipped)
+    assert _rms_ok(out["cleaned"].cpu().numpy(), want["filtered"]) <= 2e-5
+    assert np.array_equal(out["keep"].cpu().numpy().astype(bool), want["keep"])
+    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= 4.0   # three chained fp32 stages feed this PSD
+    np.testing.assert_allclose(out["bandpower"].cpu().numpy(), want["bandpower"], rtol=2e-6)
+    assert float(np.abs(out["standardized"].cpu().numpy() - want["standardized"]).max()) <= 1e-4
+    tok = out["tokens"].cpu().numpy()
+    assert tok.shape == want["tokens"].shape
+    z = out["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+    cb = shipped["vq_layer.embedding.weight"]
+    assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
+    assert (tok == want["tokens"]).mean() >= 0.95
+    assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
+
+
+def test_pipeline_full_size_properties(shipped):
+    """BASELINE-size chunk (4096 epochs of 30x1500): determinism, batch-split invariance, histogram checksum."""
+    pipe, *_ = _make_pipeline(shipped)
+    E = 4096
+    x = synth_epochs(E, 30, 1500, seed=11, device=DEV)
+    o1 = {k: v.clone() for k, v in pipe.run(x).items()}
+    pipe.reset_hist()
+    o2 = {k: v.clone() for k, v in pipe.run(x).items()}
+    for k in ("psd", "bandpower", "tokens", "keep", "hist"):
+        assert torch.equal(o1[k], o2[k]), k                      # bitwise deterministic
+    assert int(o1["hist"].sum()) == E * 375
+    assert torch.equal(o1["hist"], torch.bincount(o1["tokens"].reshape(-1), minlength=512))
+    pipe.reset_hist()
+    oa = {k: v.clone() for k, v in pipe.run(x[:1000]).items()}
+    ob = pipe.run(x[1000:1777])
+    assert torch.equal(torch.cat([oa["tokens"], ob["tokens"]]), o1["tokens"][:1777])   # epochs are independent
+    assert torch.equal(torch.cat([oa["psd"], ob["psd"]]), o1["psd"][:1777])
+    assert bool(torch.isfinite(o1["psd"]).all()) and bool((o1["psd"] > 0).all())

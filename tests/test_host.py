@@ -1,0 +1,110 @@
+"""CPU tests of the host-side logic and of the C-ABI library surface (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import lbm_amd
+from lbm_amd import _lib
+from lbm_amd.filter import notch_taps
+from oracle import eeg_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "lbm_abi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lbm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 16
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/lbm_abi.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes SIGNATURES and the header disagree"
+    assert _lib.load().lbm_version() == 1
+
+
+def test_fir_design_matches_scipy_based_oracle():
+    for fs in (250.0, 500.0, 1000.0):
+        np.testing.assert_allclose(lbm_amd.create_filter(fs, 4.0, 30.0), orc.design_fir(fs, 4.0, 30.0), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(lbm_amd.create_filter(500.0, 1.0, 40.0), orc.design_fir(500.0, 1.0, 40.0), atol=1e-15)
+    np.testing.assert_allclose(lbm_amd.create_filter(500.0, None, 30.0), orc.design_fir(500.0, None, 30.0), atol=1e-15)
+    np.testing.assert_allclose(lbm_amd.create_filter(500.0, 4.0, None), orc.design_fir(500.0, 4.0, None), atol=1e-15)
+    for a, b in zip(notch_taps(500.0, [60.0, 120.0]), orc.design_notch(500.0, [60.0, 120.0])):
+        np.testing.assert_allclose(a, b, atol=1e-15)
+    with pytest.raises(ValueError):
+        lbm_amd.create_filter(500.0, None, None)
+
+
+def test_ica_projection_matches_oracle():
+    rs = np.random.RandomState(3)
+    C = 30
+    pca = np.linalg.qr(rs.randn(C, C))[0]
+    un = rs.randn(20, 20)
+    kw = dict(unmixing=un, mixing=np.linalg.inv(un), pca_components=pca, pca_mean=rs.randn(C), pre_whitener=2e-5,
+              n_components=20, exclude=[1, 7])
+    A, b = lbm_amd.ica_projection(**kw)
+    Ao, bo = orc.ica_projection(**kw)
+    np.testing.assert_allclose(A, Ao, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(b, bo, rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(lbm_amd.average_reference_matrix(5), orc.average_reference_matrix(5))
+
+
+def test_constants_keep_reference_names_and_defaults():
+    assert (lbm_amd.FILTER_LFREQ, lbm_amd.FILTER_HFREQ, lbm_amd.NOTCH_FREQ) == (4.0, 30.0, 60.0)
+    assert (lbm_amd.TMIN, lbm_amd.TMAX, lbm_amd.BASELINE) == (-0.5, 1.5, (None, 0))
+    assert lbm_amd.REJECT_CRITERIA == dict(eeg=150e-6) and lbm_amd.PSD_WINDOW == "hann"
+    assert (lbm_amd.VQ_EMBEDDING_DIM, lbm_amd.VQ_NUM_EMBEDDINGS, lbm_amd.VQ_COMMITMENT_COST, lbm_amd.VQ_DECAY) == (256, 512, 0.25, 0.99)
+    assert lbm_amd.BATCH_SIZE == 64 and lbm_amd.n_baseline_samples(-0.5, 500.0) == 251
+
+
+def test_vqvae_loads_shipped_state_dict_unchanged(shipped):
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    sd = {k: torch.from_numpy(v) for k, v in shipped.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("decoder.") for k in missing)
+    assert set(m.state_dict()) >= {"vq_layer.embedding.weight", "vq_layer.ema_cluster_size", "vq_layer.ema_w",
+                                   "encoder.0.weight", "encoder.6.bias"}
+
+
+def test_shard_range_partitions_in_rank_order():
+    for E, W in ((10, 3), (8, 8), (5, 8), (1000000, 8), (0, 2)):
+        spans = [lbm_amd.shard_range(E, r, W) for r in range(W)]
+        assert spans[0][0] == 0 and spans[-1][1] == E
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_welch_bins_grid():
+    from lbm_amd.psd import welch_bins
+    f, lo, hi = welch_bins(500.0, 500, 4.0, 30.0)
+    assert (lo, hi) == (4, 30) and np.array_equal(f, np.arange(4.0, 31.0))
+    f, lo, hi = welch_bins(250.0, 512, 4.0, 30.0)
+    assert len(f) == 53 and (lo, hi) == (9, 61)
+    f, lo, hi = welch_bins(500.0, 512, 1.0, 40.0)
+    assert len(f) == 39
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_cpu_fallback():
+    x = np.zeros((2, 3, 64), dtype=np.float32)
+    with pytest.raises(Exception):
+        lbm_amd.filter_data(x, 500.0, 4.0, 30.0)
+    with pytest.raises(Exception):
+        lbm_amd.vq_argmin(torch.zeros(4, 256), torch.zeros(8, 256))
+
+
+def test_argument_validation_without_launch():
+    lib = _lib.load()
+    # bad arguments are rejected before anything touches a device
+    assert lib.lbm_fir_f32(None, None, 4, 100, None, 5, 0, None) == -1
+    assert b"NULL" in lib.lbm_last_error()
+    assert lib.lbm_fir_f32(None, None, 0, 100, None, 4, 0, None) == 0          # empty input is a no-op
+    assert lib.lbm_vq_argmin_f32(None, 256, 0, None, None, None, None, None, 10, 100, 512, None) == -2   # D % 8 != 0
+    assert lib.lbm_welch_f32(None, None, None, 10, 100, 500.0, 500, 500, 250, None, 4, 30, 0, None) == -1  # nfft > T
+    assert b"larger than the number of samples" in lib.lbm_last_error()
+    assert lib.lbm_welch_tables_bytes(500, 500, 4, 30) >= 64 + 4 * 1500
