@@ -67,6 +67,7 @@ class EpochPipeline:
             self.S = self.L2
         self._cap = 0
         self._buf: Dict[str, torch.Tensor] = {}
+        self.stage_events = None   # set to [] to record (name, start, end) HIP events per stage on the current stream
 
     # ------------------------------------------------------------------ buffers
     def _reserve(self, E: int):
@@ -90,6 +91,17 @@ class EpochPipeline:
     def run(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         """x: [E, C, T] float32 CUDA tensor.  Returns views into the pipeline's buffers (valid until the next run)."""
         c, lib, p, st = self.cfg, self.lib, _lib.ptr, _lib.stream_ptr()
+        ev = self.stage_events
+
+        def mark(name, start):
+            if ev is None:
+                return None
+            e_ = torch.cuda.Event(enable_timing=True)
+            e_.record()
+            if start is None:
+                return e_
+            ev.append((name, start, e_))
+            return e_
         if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
             raise ValueError("x must be a contiguous float32 CUDA tensor")
         E, C, T = x.shape
@@ -98,19 +110,25 @@ class EpochPipeline:
         self._reserve(E)
         B = {k: (v[:E] if k != "hist" else v) for k, v in self._buf.items()}
         cur = x
+        t0 = mark("", None)
         if c.do_filter:
             _lib.check(lib.lbm_fir_f32(p(cur), p(B["filt"]), E * C, T, p(self.taps), self.taps.numel(), _lib.PAD_REFLECT_LIMITED, st), "fir")
             cur = B["filt"]
+            t0 = mark("fir", t0)
         if c.do_ica:
             _lib.check(lib.lbm_affine_ch_f32(p(cur), p(B["clean"]), E, C, C, T, p(self.A), p(self.b), st), "affine")
             cur = B["clean"]
+            t0 = mark("affine", t0)
         base = B["clean"]
         _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base), p(B["std"]) if c.do_tokenize else None, p(B["keep"]), E, C, T,
                                           c.n_baseline, float(c.reject),
                                           _lib.STD_EPOCH_CHANNEL if c.do_tokenize else _lib.STD_NONE, c.zscore_eps, st), "post")
+        t0 = mark("post", t0)
         _lib.check(lib.lbm_welch_f32(p(base), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft, self.n_fft,
                                      self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, _lib.AVG_MEAN, st), "welch")
+        t0 = mark("welch", t0)
         _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
+        t0 = mark("bandpower", t0)
         out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"], "cleaned": base}
         if c.do_tokenize:
             e = self.enc
@@ -120,8 +138,10 @@ class EpochPipeline:
             conv(B["h1"], B["h2"], 2, 64, self.L1, 128, 4, 2, 1, 1)
             conv(B["h2"], B["h3"], 4, 128, self.L2, 256, 3, 1, 1, 1)
             conv(B["h3"], B["z"], 6, 256, self.L2, self.D, 1, 1, 0, 0)
+            t0 = mark("encoder", t0)
             _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.S, _lib.VQ_CHANNEL_MAJOR, p(self.codebook), p(self.ee),
                                              p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
+            t0 = mark("vq", t0)
             out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"])
         return out
 
