@@ -4,8 +4,18 @@
 //   bytes 0..7   double  sum(w^2)
 //   bytes 64..   float   window[nperseg4]            (periodic Hann / Hamming / boxcar)
 //                float   cos[nfft4], sin[nfft4]      (twiddles of 2*pi*j/nfft)
+//                float   basis[16][KD][4]            (folded DFT basis, only when nfft % 4 == 0 and nperseg == nfft)
 //
-// lbm_welch_f32: one workgroup per row.  The row's segments are mean-removed, windowed and staged in
+// Fast path (welch_fold_kernel; nfft % 4 == 0, nperseg == nfft, <= 16 even and <= 16 odd bins, mean average):
+//   two radix-2 decimation-in-frequency folds turn the N-point real DFT of the windowed segment into four
+//   real (N/4+1)-point transforms -- even bins use ce[n] = a[n]+a[H-n], se[n] = b[n]-b[H-n], odd bins
+//   co[n] = a[n]-a[H-n], so[n] = b[n]+b[H-n], with a[n] = w[n](d[n]+d[N-n]), b[n] = w[n](d[n]-d[N-n]),
+//   H = N/2 -- and only the requested bins are evaluated: [16 segments x (N/4+1)] x [(N/4+1) x 16 bins]
+//   products on v_mfma_f32_16x16x4_f32.  A wavefront stages a few whole rows in LDS (each sample read from
+//   HBM once, coalesced), folds on the fly in registers straight into the MFMA A operand (no folded image
+//   is ever stored), takes |X|^2 from the accumulators, and averages the row's segments through a small
+//   LDS buffer.  4x fewer multiply-adds than the direct pruned DFT, no bank-conflicting twiddle gathers.
+// Fallback (welch_kernel): one workgroup per row.  The row's segments are mean-removed, windowed and staged in
 // LDS; each thread then evaluates the pruned DFT (only bins bin_lo..bin_hi, e.g. 27 of 251) of
 // (segment, bin) pairs with an exact integer twiddle index (k*n mod nfft), and the segment average is
 // taken in a fixed order.
@@ -23,7 +33,13 @@ struct TableView {
     const float* window;
     const float* cosv;
     const float* sinv;
+    const float* basis;
 };
+
+// folded-basis geometry for nfft % 4 == 0
+__host__ __device__ inline int fold_qs(int nfft) { return (nfft / 4 + 1 + 3) / 4; }   // k-steps per lane quarter
+__host__ __device__ inline int fold_kd(int nfft) { return 4 * fold_qs(nfft); }        // padded transform length
+__host__ __device__ inline bool fold_ok_tables(int nfft, int nperseg) { return (nfft % 4) == 0 && nperseg == nfft && nfft >= 8; }
 __host__ __device__ inline TableView view_tables(const void* tables, int nfft, int nperseg) {
     const char* p = reinterpret_cast<const char*>(tables);
     TableView v;
@@ -31,6 +47,7 @@ __host__ __device__ inline TableView view_tables(const void* tables, int nfft, i
     v.window = reinterpret_cast<const float*>(p + kHeader);
     v.cosv = v.window + pad4(nperseg);
     v.sinv = v.cosv + pad4(nfft);
+    v.basis = v.sinv + pad4(nfft);
     return v;
 }
 
@@ -41,7 +58,8 @@ __device__ inline double window_value(int window_id, int n, int N) {
     return 1.0;
 }
 
-__global__ __launch_bounds__(kThreads) void welch_tables_kernel(void* tables, int nfft, int nperseg, int window_id) {
+__global__ __launch_bounds__(kThreads) void welch_tables_kernel(void* tables, int nfft, int nperseg, int window_id,
+                                                                int bin_lo, int bin_hi) {
     __shared__ double s_part[kThreads];
     char* p = reinterpret_cast<char*>(tables);
     float* window = reinterpret_cast<float*>(p + kHeader);
@@ -58,12 +76,165 @@ __global__ __launch_bounds__(kThreads) void welch_tables_kernel(void* tables, in
         cosv[j] = (j < nfft) ? (float)cospi(a) : 0.f;
         sinv[j] = (j < nfft) ? (float)sinpi(a) : 0.f;
     }
+    if (fold_ok_tables(nfft, nperseg)) {
+        // basis[j][n][v]: v = 0 cos (even bin), 1 sin (even bin), 2 cos (odd bin), 3 sin (odd bin); bin slot j.
+        float* basis = sinv + pad4(nfft);
+        const int KD = fold_kd(nfft), Q = nfft / 4;
+        const int ke0 = bin_lo + (bin_lo & 1), ko0 = bin_lo + 1 - (bin_lo & 1);
+        for (int i = threadIdx.x; i < 16 * KD; i += kThreads) {
+            const int j = i / KD, n = i - j * KD;
+            const int ke = ke0 + 2 * j, ko = ko0 + 2 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n <= Q) {
+                if (ke <= bin_hi) {
+                    const double a = 2.0 * (double)(((long long)ke * n) % nfft) / (double)nfft;
+                    v.x = (float)cospi(a);
+                    v.y = (float)sinpi(a);
+                }
+                if (ko <= bin_hi) {
+                    const double a = 2.0 * (double)(((long long)ko * n) % nfft) / (double)nfft;
+                    v.z = (float)cospi(a);
+                    v.w = (float)sinpi(a);
+                }
+            }
+            reinterpret_cast<float4*>(basis)[i] = v;
+        }
+    }
     s_part[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int i = 0; i < kThreads; ++i) s += s_part[i];
         *reinterpret_cast<double*>(p) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ fast path
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int kLdp = 33;  // row stride of the per-wave power buffer
+
+struct FoldGeom {
+    int N, H, Q, QS, KD, LDB;     // LDB: floats per bin row of the LDS basis image (KD*4 + pad, LDB/4 == 2 mod 16)
+    int hop, nseg, RW, TILES;     // rows per group, 16-segment MFMA tiles per group
+    int rows_floats;              // RW*T rounded up to 4
+    int wave_floats;              // LDS floats per wave
+};
+
+__host__ __device__ inline FoldGeom fold_geom(int nfft, int T, int hop, int nseg) {
+    FoldGeom g;
+    g.N = nfft; g.H = nfft / 2; g.Q = nfft / 4; g.QS = fold_qs(nfft); g.KD = 4 * g.QS;
+    int ld4 = g.KD;                       // in float4 units
+    ld4 += ((2 - ld4) % 16 + 16) % 16;    // == 2 (mod 16): conflict-free ds_read_b128 for the (bin, kq) lane map
+    g.LDB = 4 * ld4;
+    g.hop = hop; g.nseg = nseg;
+    g.RW = nseg >= 16 ? 1 : 16 / nseg;
+    g.TILES = (g.RW * nseg + 15) / 16;
+    g.rows_floats = (g.RW * T + 3) & ~3;
+    g.wave_floats = g.rows_floats + g.TILES * 16 * kLdp + g.TILES * 16;
+    return g;
+}
+
+__global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __restrict__ x, float* __restrict__ psd, int64_t rows,
+                                                              int T, double fs, FoldGeom g, const void* __restrict__ tables,
+                                                              int bin_lo, int F, int64_t ngroups) {
+    extern __shared__ __align__(16) float smem[];
+    float* s_basis = smem;                       // [16][LDB]
+    float* s_win = s_basis + 16 * g.LDB;         // [H+1] (padded to 4)
+    const int win_floats = (g.H + 1 + 3) & ~3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s_rows = s_win + win_floats + (size_t)wave * g.wave_floats;   // [RW][T]
+    float* s_P = s_rows + g.rows_floats;                                 // [TILES*16][kLdp]
+    float* s_mean = s_P + g.TILES * 16 * kLdp;                           // [TILES*16]
+
+    const TableView tv = view_tables(tables, g.N, g.N);
+    for (int i = threadIdx.x; i < 16 * g.KD; i += blockDim.x) {
+        const int jj = i / g.KD, n = i - jj * g.KD;
+        *reinterpret_cast<float4*>(s_basis + jj * g.LDB + 4 * n) = reinterpret_cast<const float4*>(tv.basis)[i];
+    }
+    for (int i = threadIdx.x; i <= g.H; i += blockDim.x) s_win[i] = tv.window[i];
+    __syncthreads();   // the only workgroup barrier: waves are independent from here on
+
+    const int j = lane & 15, kq = lane >> 4;
+    const double scale = 1.0 / (fs * (*tv.sum_w2));
+    const int waves_per_block = blockDim.x >> 6;
+    const float inv_n = 1.f / (float)g.N;
+    const int ke0 = bin_lo + (bin_lo & 1), ko0 = bin_lo + 1 - (bin_lo & 1);
+
+    for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < ngroups; grp += (int64_t)gridDim.x * waves_per_block) {
+        const int64_t row0 = grp * g.RW;
+        const int nrows = (int)((rows - row0) < g.RW ? (rows - row0) : g.RW);
+        const int nsegs = nrows * g.nseg;
+        // ---- stage the group's rows (contiguous in x) into this wave's LDS
+        {
+            const float* src = x + row0 * (int64_t)T;
+            const int nfl = nrows * T;
+            if ((((uintptr_t)src) & 15) == 0) {
+                const int n4 = nfl >> 2;
+                for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(s_rows)[i] = reinterpret_cast<const float4*>(src)[i];
+                for (int i = (n4 << 2) + lane; i < nfl; i += 64) s_rows[i] = src[i];
+            } else {
+                for (int i = lane; i < nfl; i += 64) s_rows[i] = src[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- per-segment means
+        for (int sg = 0; sg < nsegs; ++sg) {
+            const float* base = s_rows + (sg / g.nseg) * T + (sg % g.nseg) * g.hop;
+            float sum = 0.f;
+            for (int n = lane; n < g.N; n += 64) sum += base[n];
+            sum = lbm::wave_sum(sum);
+            if (lane == 0) s_mean[sg] = sum * inv_n;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- folded pruned DFT, 16 segments per MFMA tile
+        for (int tile = 0; tile < g.TILES; ++tile) {
+            const int sg = tile * 16 + j;
+            const int sgc = sg < nsegs ? sg : 0;
+            const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
+            const float m = s_mean[sgc];
+            const float* bb = s_basis + j * g.LDB;
+            f32x4 re_e = {0.f, 0.f, 0.f, 0.f}, im_e = re_e, re_o = re_e, im_o = re_e;
+#pragma unroll 2
+            for (int t = 0; t < g.QS; ++t) {
+                const int n = 4 * t + kq;
+                const int nc = n < g.Q ? n : g.Q;
+                const float d1 = base[nc] - m;
+                const float d3 = base[g.H - nc] - m;
+                float d2 = base[g.N - (nc ? nc : 1)] - m;   // d[N-n]; d[N] does not exist -> 0
+                float d4 = base[g.H + nc] - m;              // d[H+n]; at n == 0 it is d[H] again -> 0
+                if (nc == 0) { d2 = 0.f; d4 = 0.f; }
+                const float w1 = s_win[nc], w2 = s_win[g.H - nc];
+                const float a1 = w1 * (d1 + d2), a2 = w2 * (d3 + d4);
+                const float b1 = w1 * (d1 - d2), b2 = w2 * (d3 - d4);
+                const float f = (nc == g.Q) ? 0.5f : 1.f;   // the middle term pairs with itself
+                const float ce = f * (a1 + a2), co = a1 - a2, se = b1 - b2, so = f * (b1 + b2);
+                const float4 bs = *reinterpret_cast<const float4*>(bb + 4 * n);
+                re_e = __builtin_amdgcn_mfma_f32_16x16x4f32(ce, bs.x, re_e, 0, 0, 0);
+                im_e = __builtin_amdgcn_mfma_f32_16x16x4f32(se, bs.y, im_e, 0, 0, 0);
+                re_o = __builtin_amdgcn_mfma_f32_16x16x4f32(co, bs.z, re_o, 0, 0, 0);
+                im_o = __builtin_amdgcn_mfma_f32_16x16x4f32(so, bs.w, im_o, 0, 0, 0);
+            }
+            // accumulator: column = bin slot j (lane & 15), rows = segments 4*kq + r
+            const int ie = ke0 + 2 * j - bin_lo, io = ko0 + 2 * j - bin_lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float* prow = s_P + (tile * 16 + 4 * kq + r) * kLdp;
+                if (ie < F) prow[ie] = fmaf(re_e[r], re_e[r], im_e[r] * im_e[r]);
+                if (io < F) prow[io] = fmaf(re_o[r], re_o[r], im_o[r] * im_o[r]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- segment average (ascending segment order) and scaling; outputs of the group are contiguous
+        const int nout = nrows * F;
+        for (int o = lane; o < nout; o += 64) {
+            const int r = o / F, fb = o - r * F;
+            float acc = 0.f;
+            for (int s = 0; s < g.nseg; ++s) acc += s_P[(r * g.nseg + s) * kLdp + fb];
+            const int k = bin_lo + fb;
+            const double one_sided = (k == 0 || k == g.H) ? 1.0 : 2.0;
+            psd[row0 * F + o] = (float)((double)(acc / (float)g.nseg) * (scale * one_sided));
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -179,7 +350,9 @@ size_t welch_lds_bytes(int nfft, int nperseg, int nseg, int F) {
 extern "C" size_t lbm_welch_tables_bytes(int32_t nfft, int32_t nperseg, int32_t bin_lo, int32_t bin_hi) {
     (void)bin_lo; (void)bin_hi;
     if (nfft < 1 || nperseg < 1) return 0;
-    return (size_t)kHeader + ((size_t)pad4(nperseg) + 2 * (size_t)pad4(nfft)) * sizeof(float);
+    size_t floats = (size_t)pad4(nperseg) + 2 * (size_t)pad4(nfft);
+    if (fold_ok_tables(nfft, nperseg)) floats += (size_t)16 * fold_kd(nfft) * 4;
+    return (size_t)kHeader + floats * sizeof(float);
 }
 
 extern "C" int lbm_welch_tables_init(void* tables, int32_t nfft, int32_t nperseg, int32_t window_id, int32_t bin_lo,
@@ -188,7 +361,8 @@ extern "C" int lbm_welch_tables_init(void* tables, int32_t nfft, int32_t nperseg
     LBM_REQUIRE(nperseg >= 1 && nperseg <= nfft, LBM_EINVAL, "lbm_welch_tables_init: need 1 <= nperseg <= nfft");
     LBM_REQUIRE(window_id >= LBM_WIN_BOXCAR && window_id <= LBM_WIN_HAMMING, LBM_EINVAL, "lbm_welch_tables_init: unknown window_id %d", window_id);
     LBM_REQUIRE(bin_lo >= 0 && bin_lo <= bin_hi && bin_hi <= nfft / 2, LBM_EINVAL, "lbm_welch_tables_init: bins [%d,%d] outside [0,%d]", bin_lo, bin_hi, nfft / 2);
-    hipLaunchKernelGGL(welch_tables_kernel, dim3(1), dim3(kThreads), 0, lbm::as_stream(stream), tables, nfft, nperseg, window_id);
+    hipLaunchKernelGGL(welch_tables_kernel, dim3(1), dim3(kThreads), 0, lbm::as_stream(stream), tables, nfft, nperseg, window_id,
+                       bin_lo, bin_hi);
     return lbm::check_launch("lbm_welch_tables_init");
 }
 
@@ -209,6 +383,26 @@ extern "C" int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int
     const int hop = nperseg - noverlap;
     const int nseg = (T - noverlap) / hop;
     const int F = bin_hi - bin_lo + 1;
+    // fast path: folded pruned DFT on MFMA
+    const int n_even = (bin_hi / 2) - ((bin_lo + 1) / 2) + 1, n_odd = F - n_even;
+    if (fold_ok_tables(nfft, nperseg) && average_mode == LBM_AVG_MEAN && seg_or_null == nullptr && n_even <= 16 &&
+        n_odd <= 16 && nseg >= 1) {
+        const FoldGeom g = fold_geom(nfft, T, hop, nseg);
+        const size_t shared_floats = (size_t)16 * g.LDB + ((g.H + 1 + 3) & ~3);
+        int waves = 4;
+        while (waves > 1 && (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float) > 160 * 1024) waves >>= 1;
+        const size_t lds_f = (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float);
+        if (lds_f <= 160 * 1024) {
+            const int64_t ngroups = (rows + g.RW - 1) / g.RW;
+            int64_t blocks = (ngroups + waves - 1) / waves;
+            if (blocks > 1024) blocks = 1024;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(welch_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
+            if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_welch_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(welch_fold_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_f, lbm::as_stream(stream), x, psd, rows, T,
+                               (double)fs, g, tables, bin_lo, F, ngroups);
+            return lbm::check_launch("lbm_welch_f32(fold)");
+        }
+    }
     const size_t lds = welch_lds_bytes(nfft, nperseg, nseg, F);
     LBM_REQUIRE(lds <= 160 * 1024, LBM_EUNSUPPORTED, "lbm_welch_f32: row needs %zu B of LDS (max 163840)", lds);
     if (lds > 64 * 1024) {
