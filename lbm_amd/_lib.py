@@ -28,6 +28,9 @@ SIGNATURES = {
     "lbm_version": (C.c_int, []),
     "lbm_last_error": (C.c_char_p, []),
     "lbm_fir_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _i32, _p]),
+    "lbm_fir_fft_tables_bytes": (C.c_size_t, [_i32, _i32]),
+    "lbm_fir_fft_tables_init": (C.c_int, [_p, _p, _i32, _i32, _p]),
+    "lbm_fir_fft_f32": (C.c_int, [_p, _p, _i64, _i32, _p, _i32, _i32, _p]),
     "lbm_affine_ch_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _p, _p, _p]),
     "lbm_epoch_post_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _p]),
     "lbm_channel_moments_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p]),

@@ -99,8 +99,30 @@ def create_filter(sfreq: float, l_freq: Optional[float], h_freq: Optional[float]
     return _compose(n_taps, fn, gain, fir_window)
 
 
-def fir_apply(data, taps, pad: str = "reflect_limited"):
-    """Apply symmetric odd-length FIR taps along the last axis of a CUDA/array tensor (fp32 on device)."""
+FFT_MIN_TAPS = 65      # below this the direct LDS form (lbm_fir_f32) does less work than a 1024-point transform
+
+
+def fir_fft_tables(taps_dev: torch.Tensor, T: int) -> Optional[torch.Tensor]:
+    """Device table buffer for ``lbm_fir_fft_f32`` (DFT of the taps + twiddles), or None if the
+    (T, ntaps) pair is outside what the fast-convolution kernel supports."""
+    lib = _lib.load()
+    n = int(taps_dev.numel())
+    nbytes = int(lib.lbm_fir_fft_tables_bytes(int(T), n))
+    if nbytes == 0:
+        return None
+    tab = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=taps_dev.device)
+    _lib.check(lib.lbm_fir_fft_tables_init(_lib.ptr(tab), _lib.ptr(taps_dev), int(T), n, _lib.stream_ptr()),
+               "lbm_fir_fft_tables_init")
+    return tab
+
+
+def fir_apply(data, taps, pad: str = "reflect_limited", method: str = "auto"):
+    """Apply symmetric odd-length FIR taps along the last axis of a CUDA/array tensor (fp32 on device).
+
+    method: 'fft' = fast convolution (``lbm_fir_fft_f32``, what MNE's overlap-add does), 'direct' = LDS-staged
+    direct form (``lbm_fir_f32``), 'auto' = fft for >= FFT_MIN_TAPS taps when supported, else direct."""
+    if method not in ("auto", "fft", "direct"):
+        raise ValueError(f"method must be 'auto', 'fft' or 'direct', got {method!r}")
     pad_mode = {"reflect_limited": _lib.PAD_REFLECT_LIMITED, "zero": _lib.PAD_ZERO}[pad]
     was_numpy = not isinstance(data, torch.Tensor)
     x = _lib.dev_f32(data)
@@ -109,8 +131,18 @@ def fir_apply(data, taps, pad: str = "reflect_limited"):
     t = torch.as_tensor(np.asarray(taps, dtype=np.float64), dtype=torch.float64).to(x.device).to(torch.float32) \
         if not (isinstance(taps, torch.Tensor) and taps.is_cuda) else taps.to(torch.float32).contiguous()
     y = torch.empty_like(x)
-    _lib.check(_lib.load().lbm_fir_f32(_lib.ptr(x), _lib.ptr(y), rows, T, _lib.ptr(t), t.numel(), pad_mode,
-                                       _lib.stream_ptr()), "lbm_fir_f32")
+    lib = _lib.load()
+    tab = None
+    if rows and method != "direct" and (method == "fft" or t.numel() >= FFT_MIN_TAPS):
+        tab = fir_fft_tables(t, T)
+        if tab is None and method == "fft":
+            raise NotImplementedError(f"fast-convolution FIR does not support ntaps={t.numel()} (use method='direct')")
+    if tab is not None:
+        _lib.check(lib.lbm_fir_fft_f32(_lib.ptr(x), _lib.ptr(y), rows, T, _lib.ptr(tab), t.numel(), pad_mode,
+                                       _lib.stream_ptr()), "lbm_fir_fft_f32")
+    else:
+        _lib.check(lib.lbm_fir_f32(_lib.ptr(x), _lib.ptr(y), rows, T, _lib.ptr(t), t.numel(), pad_mode,
+                                   _lib.stream_ptr()), "lbm_fir_f32")
     return y.cpu().numpy().astype(np.float64) if was_numpy else y
 
 

@@ -35,6 +35,7 @@ class PipelineConfig:
     do_tokenize: bool = True
     do_filter: bool = True
     do_ica: bool = True
+    fir_method: str = "fft"            # 'fft' (fast convolution) or 'direct' (LDS direct form)
 
 
 class EpochPipeline:
@@ -44,6 +45,10 @@ class EpochPipeline:
         self.lib = _lib.load()
         f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).to(self.dev, torch.float32).contiguous()  # noqa: E731
         self.taps = f32(taps) if taps is not None else None
+        self.fir_tab = None
+        if self.taps is not None and cfg.do_filter and cfg.fir_method == "fft":
+            from .filter import fir_fft_tables
+            self.fir_tab = fir_fft_tables(self.taps, cfg.n_times)   # None -> direct form
         self.A = f32(A) if A is not None else None
         self.b = f32(b) if b is not None else None
         self.n_fft = int(cfg.sfreq) if cfg.n_fft is None else int(cfg.n_fft)
@@ -112,7 +117,12 @@ class EpochPipeline:
         cur = x
         t0 = mark("", None)
         if c.do_filter:
-            _lib.check(lib.lbm_fir_f32(p(cur), p(B["filt"]), E * C, T, p(self.taps), self.taps.numel(), _lib.PAD_REFLECT_LIMITED, st), "fir")
+            if self.fir_tab is not None:
+                _lib.check(lib.lbm_fir_fft_f32(p(cur), p(B["filt"]), E * C, T, p(self.fir_tab), self.taps.numel(),
+                                               _lib.PAD_REFLECT_LIMITED, st), "fir_fft")
+            else:
+                _lib.check(lib.lbm_fir_f32(p(cur), p(B["filt"]), E * C, T, p(self.taps), self.taps.numel(),
+                                           _lib.PAD_REFLECT_LIMITED, st), "fir")
             cur = B["filt"]
             t0 = mark("fir", t0)
         if c.do_ica:

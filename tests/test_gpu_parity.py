@@ -38,16 +38,37 @@ def _rms_ok(got, want, tol=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------ a1 / a2 FIR
+@pytest.mark.parametrize("method", ["fft", "direct"])
 @pytest.mark.parametrize("T", [1500, 1001, 300, 37, 1, 4100])
-def test_fir_bandpass_matches_oracle(T):
+def test_fir_bandpass_matches_oracle(T, method):
     x = synth_epochs(3, 5, T, seed=1).numpy() if T > 8 else np.random.RandomState(0).randn(3, 5, T).astype(np.float32)
     taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
-    y = lbm_amd.fir_apply(torch.from_numpy(x).to(DEV), taps).cpu().numpy()
+    y = lbm_amd.fir_apply(torch.from_numpy(x).to(DEV), taps, method=method).cpu().numpy()
     want = orc.fir_zero_phase(x.astype(np.float64), taps)
     scale = np.sqrt((x.astype(np.float64) ** 2).mean()) + 1e-300
     # short rows are dominated by the padding transient: compare against the input scale there
     err = _rms_ok(y, want) if T >= 1001 else float(np.abs(y - want).max() / scale)
     assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("fs,T,lo,hi", [(1000.0, 10000, 4.0, 30.0),    # config L: 1651 taps, 4096-point transform, 3 block pairs
+                                        (250.0, 2000, 4.0, 30.0),      # preprocessing_unsupervised.py after resample: 413 taps
+                                        (500.0, 1001, 1.0, 40.0),      # multi-train/CLEAN.py:59: 1651 taps
+                                        (100.0, 555, 8.0, None),       # high-pass, short filter -> 1024-point transform
+                                        (100.0, 64, None, 20.0)])      # T shorter than the filter
+def test_fir_fft_plans_match_oracle_and_direct(fs, T, lo, hi):
+    """Every transform size (1024 / 2048 / 4096) and multi-pair rows of the fast-convolution kernel."""
+    x = synth_epochs(2, 3, T, sfreq=fs, seed=21).numpy()
+    taps = lbm_amd.create_filter(fs, lo, hi)
+    xd = torch.from_numpy(x).to(DEV)
+    want = orc.fir_zero_phase(x.astype(np.float64), taps)
+    scale = np.sqrt((x.astype(np.float64) ** 2).mean()) + 1e-300
+    for method in ("fft", "direct"):
+        y = lbm_amd.fir_apply(xd, taps, method=method).cpu().numpy()
+        assert float(np.abs(y - want).max() / scale) <= 1e-5, (method, len(taps))
+    yz = lbm_amd.fir_apply(xd, taps, pad="zero", method="fft").cpu().numpy()
+    yzd = lbm_amd.fir_apply(xd, taps, pad="zero", method="direct").cpu().numpy()
+    assert float(np.abs(yz - yzd).max() / scale) <= 1e-5
 
 
 def test_fir_notch_and_zero_pad_and_via_filter_data():
