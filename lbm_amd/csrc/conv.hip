@@ -34,7 +34,7 @@ struct ConvCfg {
     static constexpr int A_F4 = BM * KC / 4 / kThreads;  // float4 per thread per chunk (weights)
     static constexpr int X_IT = (CK * XW + kThreads - 1) / kThreads;
     static constexpr int MS = BM / 64;                   // 32-row MFMA tiles per wave along M (wave tile = BM/2 x 64)
-    static constexpr size_t LDS_FLOATS = 2 * (size_t)(BM * LDA + CK * XWP);
+    static constexpr size_t LDS_FLOATS = 2 * (size_t)(BM * LDA + CK * XWP) + BM;   // + bias tile
     static_assert(KC % 8 == 0, "each lane half consumes KC/2 k-steps in groups of 4");
     static_assert((BM * KC / 4) % kThreads == 0, "weight slab must split evenly");
 };
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
     extern __shared__ __align__(16) float smem[];
     float* const s_a0 = smem;                 // 2 x [BM][LDA]
     float* const s_x0 = smem + 2 * BM * LDA;  // 2 x [CK][XWP]
+    float* const s_bias = smem + Cfg::LDS_FLOATS - BM;   // [BM], visible after the first barrier of the chunk loop
 
     const int Ktot = Cin * KS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -63,9 +64,18 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
     const int g0 = p0 * STRIDE - pad;
     const float* xb = x + b * (int64_t)Cin * Lin;
 
+    if (threadIdx.x < BM) {
+        const int co = m0 + threadIdx.x;
+        float bv = 0.f;
+        if (bias != nullptr && co < Cout) bv = bias[co];
+        s_bias[threadIdx.x] = bv;
+    }
+
     float4 ra[Cfg::A_F4];
     float rx[Cfg::X_IT];
 
+    // Loads are unconditional on clamped addresses and masked afterwards: a "load or zero" select would make
+    // the compiler branch around every load and drain vmcnt per element.
     auto load_chunk = [&](int ci0) {
         const int kk0 = ci0 * KS;
 #pragma unroll
@@ -73,15 +83,20 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
             const int f = threadIdx.x + i * kThreads;  // float4 index in the [BM][KC/4] slab
             const int m = f / (KC / 4), c4 = f - m * (KC / 4);
             const int co = m0 + m, kk = kk0 + 4 * c4;
-            ra[i] = (co < Cout && kk < Ktot) ? *reinterpret_cast<const float4*>(w + (int64_t)co * Ktot + kk)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = co < Cout && kk < Ktot;
+            const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)(ok ? co : 0) * Ktot + (ok ? kk : 0));
+            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::X_IT; ++i) {
             const int f = threadIdx.x + i * kThreads;
             const int r = f / XW, c = f - r * XW;
             const int ci = ci0 + r, g = g0 + c;
-            rx[i] = (r < CK && ci < Cin && g >= 0 && g < Lin) ? xb[(int64_t)ci * Lin + g] : 0.f;
+            const bool ok = r < CK && ci < Cin && g >= 0 && g < Lin;
+            const int cic = ci < Cin ? ci : Cin - 1;
+            const int gc = g < 0 ? 0 : (g < Lin ? g : Lin - 1);
+            const float v = xb[(int64_t)cic * Lin + gc];
+            rx[i] = ok ? v : 0.f;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -140,7 +155,11 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
         }
     }
 
+    // Epilogue: bias comes from the LDS tile staged at kernel start (a global load per element would drain
+    // vmcnt 16*MS*2 times); stores carry no waits.  Each store instruction writes two 128-byte row segments.
     float* yb = y + b * (int64_t)Cout * Lout;
+    const float lo = relu ? 0.f : -INFINITY;
+    const bool full_m = m0 + BM <= Cout;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int p = p0 + wn * 64 + n * 32 + j;
@@ -148,12 +167,18 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
 #pragma unroll
         for (int a = 0; a < MS; ++a) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * (BM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (co < Cout) {
-                    float v = acc[a][n][r] + (bias != nullptr ? bias[co] : 0.f);
-                    if (relu) v = fmaxf(v, 0.f);
-                    yb[(int64_t)co * Lout + p] = v;
+            for (int rq = 0; rq < 4; ++rq) {
+                const int cl = wm * (BM / 2) + a * 32 + 8 * rq + 4 * h;
+                const float4 bq = *reinterpret_cast<const float4*>(s_bias + cl);
+                const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+                float* yp = yb + (int64_t)(m0 + cl) * Lout + p;
+                if (full_m) {
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri) yp[(int64_t)ri * Lout] = fmaxf(acc[a][n][4 * rq + ri] + bv[ri], lo);
+                } else {
+#pragma unroll
+                    for (int ri = 0; ri < 4; ++ri)
+                        if (m0 + cl + ri < Cout) yp[(int64_t)ri * Lout] = fmaxf(acc[a][n][4 * rq + ri] + bv[ri], lo);
                 }
             }
         }

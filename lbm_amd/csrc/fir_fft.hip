@@ -47,16 +47,17 @@ bool make_plan(int T, int ntaps, FftPlan* out) {
     return found;
 }
 
-__device__ __forceinline__ float padded_sample(const float* __restrict__ xr, int m, int T, int pad_mode, float x0,
-                                               float xl) {
-    if (m >= 0 && m < T) return xr[m];
-    if (pad_mode != LBM_PAD_REFLECT_LIMITED) return 0.f;
-    if (m < 0) {
-        const int mm = -m;
-        return (mm <= T - 1) ? 2.f * x0 - xr[mm] : 0.f;
-    }
-    const int mm = 2 * (T - 1) - m;
-    return (mm >= 0) ? 2.f * xl - xr[mm] : 0.f;
+// Sample m of the padded row, branch-free: ONE unconditional load at a clamped index, then selects (a
+// "load or zero" conditional would make the compiler branch around each of the 32 loads and drain vmcnt).
+__device__ __forceinline__ float padded_sample(const float* __restrict__ xr, int m, int T, bool reflect, float x0,
+                                               float xl, bool live) {
+    const bool left = m < 0, right = m >= T;
+    const int idx = left ? -m : (right ? 2 * (T - 1) - m : m);
+    const bool ok = idx >= 0 && idx < T;
+    const float v = xr[ok ? idx : 0];
+    const float refl = 2.f * (left ? x0 : xl) - v;
+    const float out = (left || right) ? (reflect ? refl : 0.f) : v;
+    return (ok && live) ? out : 0.f;
 }
 
 // tables: float2 [N] Hq | [16][Q] stage-1 twiddles | [16][R3] stage-2 twiddles
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
     __syncthreads();
 
     const int half = (ntaps - 1) >> 1;
+    const bool reflect = pad_mode == LBM_PAD_REFLECT_LIMITED;
     const int seg = Lb + ntaps - 1;      // input samples a block needs (<= N)
     const int k1 = t / R3, n3 = t % R3;  // stage-2 role of this thread
 
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
         for (int n1 = 0; n1 < 16; ++n1) {
             const int p = t + Q * n1;
             const bool in = p < seg;
-            re[n1] = (in && has_a) ? padded_sample(xr, a0 - half + p, T, pad_mode, x0, xl) : 0.f;
-            im[n1] = (in && has_b) ? padded_sample(xr, b0 - half + p, T, pad_mode, x0, xl) : 0.f;
+            re[n1] = padded_sample(xr, a0 - half + p, T, reflect, x0, xl, in && has_a);
+            im[n1] = padded_sample(xr, b0 - half + p, T, reflect, x0, xl, in && has_b);
         }
 
         // ---- forward stage 1

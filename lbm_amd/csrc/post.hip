@@ -28,7 +28,10 @@ __device__ __forceinline__ float row_reduce(float v, int op, float* s_red) {
     return v;
 }
 
-template <int TPR, int NV>
+// VEC = 4: rows are 16-byte aligned and T % 4 == 0, every lane moves float4 (16 B/lane streaming);
+// VEC = 1: any T / alignment.  Loads are unconditional at a clamped index and masked afterwards (a
+// load inside `if (t < T)` makes the compiler branch and drain vmcnt per element).
+template <int TPR, int NV, int VEC>
 __global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void post_kernel(const float* __restrict__ x, float* y_base,
                                                                       float* y_std, uint8_t* __restrict__ keep,
                                                                       int64_t rows, int C, int T, int nb,
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void post_kernel(const float
     __shared__ float s_red[16];
     constexpr int BLOCK = TPR < 256 ? 256 : TPR;
     constexpr int RPB = BLOCK / TPR;
+    constexpr int NI = NV / VEC;
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
     if (row >= rows) return;  // uniform per row group (wave when TPR == 64, block otherwise)
     const int l = threadIdx.x % TPR;
@@ -44,15 +48,32 @@ __global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void post_kernel(const float
     float v[NV];
     float bsum = 0.f, tsum = 0.f, vmin = INFINITY, vmax = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int t = i * TPR + l;
-        v[i] = 0.f;
-        if (t < T) {
-            v[i] = xr[t];
-            tsum += v[i];
-            if (t < nb) bsum += v[i];
-            vmin = fminf(vmin, v[i]);
-            vmax = fmaxf(vmax, v[i]);
+    for (int i = 0; i < NI; ++i) {
+        const int t0 = (i * TPR + l) * VEC;
+        const int tc = t0 < T ? t0 : 0;   // VEC == 4: T % 4 == 0, so a quad is in range or out as a whole
+        if constexpr (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(xr + tc);
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        } else {
+            v[i] = xr[tc];
+        }
+    }
+    // all loads are in flight before the first use; the empty asm pins each loaded value so the compiler
+    // cannot sink a load back under its `t0 < T` select
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(v[i]));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int t0 = (i * TPR + l) * VEC;
+        const bool ok = t0 < T;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float val = ok ? v[VEC * i + e] : 0.f;
+            v[VEC * i + e] = val;
+            tsum += val;
+            bsum += (t0 + e < nb) ? val : 0.f;
+            vmin = fminf(vmin, ok ? val : INFINITY);
+            vmax = fmaxf(vmax, ok ? val : -INFINITY);
         }
     }
     tsum = row_reduce<TPR>(tsum, 0, s_red);
@@ -66,22 +87,37 @@ __global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void post_kernel(const float
     const float mean = tsum / (float)T - base;  // mean of the baseline-corrected row
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int t = i * TPR + l;
-        if (t < T) {
-            v[i] -= base;
-            if (y_base != nullptr) y_base[row * (int64_t)T + t] = v[i];
-            const float d = v[i] - mean;
+    for (int i = 0; i < NI; ++i) {
+        const int t0 = (i * TPR + l) * VEC;
+        const bool ok = t0 < T;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[VEC * i + e] -= base;
+            const float d = ok ? v[VEC * i + e] - mean : 0.f;
             ss = fmaf(d, d, ss);
+        }
+        if (ok && y_base != nullptr) {
+            if constexpr (VEC == 4)
+                *reinterpret_cast<float4*>(y_base + row * (int64_t)T + t0) =
+                    make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            else
+                y_base[row * (int64_t)T + t0] = v[i];
         }
     }
     if (y_std == nullptr || std_mode != LBM_STD_EPOCH_CHANNEL) return;
     ss = row_reduce<TPR>(ss, 0, s_red);
     const float denom = sqrtf(ss / (float)T) + eps;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int t = i * TPR + l;
-        if (t < T) y_std[row * (int64_t)T + t] = (v[i] - mean) / denom;
+    for (int i = 0; i < NI; ++i) {
+        const int t0 = (i * TPR + l) * VEC;
+        if (t0 < T) {
+            if constexpr (VEC == 4)
+                *reinterpret_cast<float4*>(y_std + row * (int64_t)T + t0) =
+                    make_float4((v[4 * i] - mean) / denom, (v[4 * i + 1] - mean) / denom, (v[4 * i + 2] - mean) / denom,
+                                (v[4 * i + 3] - mean) / denom);
+            else
+                y_std[row * (int64_t)T + t0] = (v[i] - mean) / denom;
+        }
     }
 }
 
@@ -154,8 +190,13 @@ int launch_post(const float* x, float* y_base, float* y_std, uint8_t* keep, int6
     constexpr int RPB = BLOCK / TPR;
     const int64_t blocks = (rows + RPB - 1) / RPB;
     if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_epoch_post_f32: grid too large");
-    hipLaunchKernelGGL((post_kernel<TPR, kNV>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, x, y_base, y_std, keep, rows,
-                       C, T, nb, thresh, std_mode, eps);
+    const bool vec = (T % 4 == 0) && (((uintptr_t)x | (uintptr_t)y_base | (uintptr_t)y_std) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL((post_kernel<TPR, kNV, 4>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, x, y_base, y_std, keep,
+                           rows, C, T, nb, thresh, std_mode, eps);
+    else
+        hipLaunchKernelGGL((post_kernel<TPR, kNV, 1>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, x, y_base, y_std, keep,
+                           rows, C, T, nb, thresh, std_mode, eps);
     return lbm::check_launch("lbm_epoch_post_f32");
 }
 

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Run ONE stage of the pipeline repeatedly on resident synthetic data (for rocprofv3 --pmc / --kernel-trace).
+
+    python tools/kbench.py --stage vq|conv1|conv2|conv3|conv4|fir|fir_direct|affine|post|welch --epochs 16384 --reps 5
+Prints the HIP-event average per launch.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import lbm_amd  # noqa: E402
+from lbm_amd import _lib  # noqa: E402
+from lbm_amd.synth import synth_epochs, synth_ica  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stage", required=True)
+    ap.add_argument("--epochs", type=int, default=16384)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    lib, p, st = _lib.load(), _lib.ptr, _lib.stream_ptr()
+    E, C, T = args.epochs, 30, 1500
+    with np.load(os.path.join(ROOT, "tests", "golden", "vq_vae_shipped.npz")) as f:
+        w = {k: torch.from_numpy(f[k]).to(dev) for k in f.files}
+    g = torch.Generator(device=dev).manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    L1, S = 750, 375
+    s = args.stage
+    if s in ("fir", "fir_direct", "affine", "post", "welch"):
+        x = synth_epochs(E, C, T, seed=3, device=dev, chunk=2048)
+        y = torch.empty_like(x)
+    if s == "vq":
+        z = rnd(E, 256, S)
+        cb = w["vq_layer.embedding.weight"].contiguous()
+        ee = torch.empty(512, device=dev)
+        lib.lbm_rownorm2_f32(p(cb), p(ee), 512, 256, st)
+        tok = torch.empty(E, S, dtype=torch.int64, device=dev)
+        fn = lambda: lib.lbm_vq_argmin_f32(p(z), S, _lib.VQ_CHANNEL_MAJOR, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
+    elif s.startswith("conv"):
+        i = int(s[4]) - 1
+        cin, lin, cout, ks, sd, pd, relu = [(30, 1500, 64, 4, 2, 1, 1), (64, 750, 128, 4, 2, 1, 1), (128, 375, 256, 3, 1, 1, 1),
+                                            (256, 375, 256, 1, 1, 0, 0)][i]
+        xin = rnd(E, cin, lin)
+        lout = (lin + 2 * pd - ks) // sd + 1
+        yo = torch.empty(E, cout, lout, device=dev)
+        wt, bs = w[f"encoder.{2 * i}.weight"].contiguous(), w[f"encoder.{2 * i}.bias"].contiguous()
+        fn = lambda: lib.lbm_conv1d_f32(p(xin), p(wt), p(bs), p(yo), E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
+    elif s in ("fir", "fir_direct"):
+        taps = torch.as_tensor(lbm_amd.create_filter(500.0, 4.0, 30.0)).to(dev, torch.float32)
+        if s == "fir":
+            tab = lbm_amd.filter.fir_fft_tables(taps, T)
+            fn = lambda: lib.lbm_fir_fft_f32(p(x), p(y), E * C, T, p(tab), taps.numel(), 0, st)  # noqa: E731
+        else:
+            fn = lambda: lib.lbm_fir_f32(p(x), p(y), E * C, T, p(taps), taps.numel(), 0, st)  # noqa: E731
+    elif s == "affine":
+        A, b = lbm_amd.ica_projection(**synth_ica(C))
+        A = torch.as_tensor(A).to(dev, torch.float32).contiguous()
+        b = torch.as_tensor(b).to(dev, torch.float32).contiguous()
+        fn = lambda: lib.lbm_affine_ch_f32(p(x), p(y), E, C, C, T, p(A), p(b), st)  # noqa: E731
+    elif s == "post":
+        y2 = torch.empty_like(x)
+        keep = torch.empty(E, dtype=torch.uint8, device=dev)
+        fn = lambda: lib.lbm_epoch_post_f32(p(x), p(y), p(y2), p(keep), E, C, T, 251, 150e-6, 1, 1e-6, st)  # noqa: E731
+    elif s == "welch":
+        from lbm_amd.psd import welch_bins, welch_tables
+        _, lo, hi = welch_bins(500.0, 500, 4.0, 30.0)
+        tab = welch_tables(dev, 500, 500, "hann", lo, hi)
+        psd = torch.empty(E, C, hi - lo + 1, device=dev)
+        fn = lambda: lib.lbm_welch_f32(p(x), p(psd), None, E * C, T, 500.0, 500, 500, 250, p(tab), lo, hi, 0, st)  # noqa: E731
+    else:
+        raise SystemExit(f"unknown stage {s}")
+    rc = fn()
+    assert rc == 0, _lib.load().lbm_last_error()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{s}: {e0.elapsed_time(e1) / args.reps:.4f} ms per launch ({E} epochs)")
+
+
+if __name__ == "__main__":
+    main()
