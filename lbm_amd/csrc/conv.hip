@@ -74,43 +74,61 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
     float4 ra[Cfg::A_F4];
     float rx[Cfg::X_IT];
 
-    // Loads are unconditional on clamped addresses and masked afterwards: a "load or zero" select would make
-    // the compiler branch around every load and drain vmcnt per element.
-    auto load_chunk = [&](int ci0) {
-        const int kk0 = ci0 * KS;
+    // Loop-invariant staging coordinates of this thread (hoisted: the chunk loop only adds a uniform base).
+    int a_off[Cfg::A_F4], a_lds[Cfg::A_F4], a_k[Cfg::A_F4];
+    bool a_ok[Cfg::A_F4];
 #pragma unroll
-        for (int i = 0; i < Cfg::A_F4; ++i) {
-            const int f = threadIdx.x + i * kThreads;  // float4 index in the [BM][KC/4] slab
-            const int m = f / (KC / 4), c4 = f - m * (KC / 4);
-            const int co = m0 + m, kk = kk0 + 4 * c4;
-            const bool ok = co < Cout && kk < Ktot;
-            const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)(ok ? co : 0) * Ktot + (ok ? kk : 0));
-            ra[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int i = 0; i < Cfg::A_F4; ++i) {
+        const int f = threadIdx.x + i * kThreads;  // float4 index in the [BM][KC/4] slab
+        const int m = f / (KC / 4), c4 = f - m * (KC / 4);
+        a_ok[i] = m0 + m < Cout;
+        a_off[i] = (a_ok[i] ? m0 + m : 0) * Ktot + 4 * c4;
+        a_lds[i] = m * LDA + 4 * c4;
+        a_k[i] = 4 * c4;
+    }
+    int x_off[Cfg::X_IT], x_lds[Cfg::X_IT];
+    bool x_ok[Cfg::X_IT];
 #pragma unroll
-        for (int i = 0; i < Cfg::X_IT; ++i) {
-            const int f = threadIdx.x + i * kThreads;
-            const int r = f / XW, c = f - r * XW;
-            const int ci = ci0 + r, g = g0 + c;
-            const bool ok = r < CK && ci < Cin && g >= 0 && g < Lin;
-            const int cic = ci < Cin ? ci : Cin - 1;
-            const int gc = g < 0 ? 0 : (g < Lin ? g : Lin - 1);
-            const float v = xb[(int64_t)cic * Lin + gc];
-            rx[i] = ok ? v : 0.f;
-        }
+    for (int i = 0; i < Cfg::X_IT; ++i) {
+        const int f = threadIdx.x + i * kThreads;
+        const int r = f / XW, c = f - r * XW;
+        const int g = g0 + c;
+        x_ok[i] = r < CK && g >= 0 && g < Lin;
+        x_off[i] = (r < CK ? r : CK - 1) * Lin + (g < 0 ? 0 : (g < Lin ? g : Lin - 1));
+        x_lds[i] = (r < CK ? r : CK - 1) * XWP + c;
+    }
+
+    // Chunk ch covers input channels [ch*CK, ch*CK+CK).  A ragged last chunk is shifted down to end at Cin
+    // (needs Cin >= CK) and the weights of the channels it shares with the previous chunk are zeroed, so
+    // every x row read is a real row.  Loads are unconditional and masked afterwards: a "load or zero"
+    // select would make the compiler branch around every load and drain vmcnt per element.
+    auto load_chunk = [&](int ch) {
+        const int cn = ch * CK;
+        const int ci0 = cn + CK <= Cin ? cn : Cin - CK;
+        const float* wc = w + ci0 * KS;
+        const float* xc = xb + (int64_t)ci0 * Lin;
+#pragma unroll
+        for (int i = 0; i < Cfg::A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(wc + a_off[i]);
+#pragma unroll
+        for (int i = 0; i < Cfg::X_IT; ++i) rx[i] = xc[x_off[i]];
     };
-    auto store_chunk = [&](int buf) {
+    // Writes the registers loaded by load_chunk(ch) to LDS image `buf`, masking here (not at the load): the
+    // empty asm pins each loaded value so the compiler cannot sink a load back under its mask.
+    auto store_chunk = [&](int buf, int ch) {
+        const int cn = ch * CK;
+        const int shift = (cn + CK <= Cin ? 0 : cn + CK - Cin) * KS;   // k entries the shifted chunk re-reads
+        float* sa = s_a0 + buf * (BM * LDA);
+        float* sx = s_x0 + buf * (CK * XWP);
 #pragma unroll
         for (int i = 0; i < Cfg::A_F4; ++i) {
-            const int f = threadIdx.x + i * kThreads;
-            const int m = f / (KC / 4), c4 = f - m * (KC / 4);
-            *reinterpret_cast<float4*>(s_a0 + buf * (BM * LDA) + m * LDA + 4 * c4) = ra[i];
+            asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+            const bool ok = a_ok[i] && a_k[i] >= shift;
+            *reinterpret_cast<float4*>(sa + a_lds[i]) = ok ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::X_IT; ++i) {
-            const int f = threadIdx.x + i * kThreads;
-            const int r = f / XW, c = f - r * XW;
-            if (r < CK) s_x0[buf * (CK * XWP) + r * XWP + c] = rx[i];
+            asm volatile("" : "+v"(rx[i]));
+            if (threadIdx.x + i * kThreads < CK * XW) sx[x_lds[i]] = x_ok[i] ? rx[i] : 0.f;
         }
     };
 
@@ -122,18 +140,12 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][n][r] = 0.f;
 
-    const int nchunks = (Cin + CK - 1) / CK;
-    load_chunk(0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        store_chunk(buf);
-        __syncthreads();
-        if (ch + 1 < nchunks) load_chunk((ch + 1) * CK);  // stays in flight under the MFMAs below
-
+    // k-steps [4*qlo, 4*qhi) of this lane half's list, from LDS image `buf`
+    auto mfma_block = [&](int buf, int qlo, int qhi) {
         const float* ap = s_a0 + buf * (BM * LDA) + (wm * (BM / 2) + j) * LDA + h * (KC / 2);
         const float* bp = s_x0 + buf * (CK * XWP) + (h * (CK / 2)) * XWP + (wn * 64 + j) * STRIDE;
 #pragma unroll
-        for (int q = 0; q < KC / 8; ++q) {
+        for (int q = qlo; q < qhi; ++q) {
             float av[MS][4];
 #pragma unroll
             for (int a = 0; a < MS; ++a) {
@@ -153,7 +165,26 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
                 }
             }
         }
+    };
+
+    // Software pipeline, one barrier per chunk: while chunk ch is multiplied out of LDS image ch&1, chunk
+    // ch+1 (loaded one iteration ago, in registers) is written to the other image and chunk ch+2's global
+    // loads are issued -- all in the middle of the MFMA stream, so staging runs in the MFMAs' shadow.
+    constexpr int QN = KC / 8, QH = QN / 2;
+    const int nchunks = (Cin + CK - 1) / CK;
+    load_chunk(0);
+    store_chunk(0, 0);
+    __syncthreads();
+    load_chunk(nchunks > 1 ? 1 : 0);
+    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+        const int buf = ch & 1;
+        mfma_block(buf, 0, QH);
+        store_chunk(buf ^ 1, ch + 1);
+        load_chunk(ch + 2 < nchunks ? ch + 2 : nchunks - 1);   // the tail re-reads the last chunk (unused)
+        mfma_block(buf, QH, QN);
+        __syncthreads();
     }
+    mfma_block((nchunks - 1) & 1, 0, QN);
 
     // Epilogue: bias comes from the LDS tile staged at kernel start (a global load per element would drain
     // vmcnt 16*MS*2 times); stores carry no waits.  Each store instruction writes two 128-byte row segments.
@@ -316,11 +347,14 @@ extern "C" int lbm_conv1d_f32(const float* x, const float* w, const float* bias,
     hipStream_t st = lbm::as_stream(stream);
     const bool w_vec = (((uintptr_t)w & 15) == 0) && ((Cin * ksize) % 4 == 0);
     if (w_vec) {
+        const int ck = ksize == 1 ? 32 : 8;   // ConvCfg::CK: a ragged last chunk is shifted, which needs Cin >= CK
+        if (Cin < ck) goto generic;
         if (ksize == 4 && stride == 2 && Cout <= 64) return launch_tile<4, 2, 64>(x, w, bias, y, B, Cin, Lin, Cout, Lout, pad, relu, st);
         if (ksize == 4 && stride == 2) return launch_tile<4, 2, 128>(x, w, bias, y, B, Cin, Lin, Cout, Lout, pad, relu, st);
         if (ksize == 3 && stride == 1 && Cin % 4 == 0) return launch_tile<3, 1, 128>(x, w, bias, y, B, Cin, Lin, Cout, Lout, pad, relu, st);
         if (ksize == 1 && stride == 1) return launch_tile<1, 1, 128>(x, w, bias, y, B, Cin, Lin, Cout, Lout, pad, relu, st);
     }
+generic:
     const int64_t Ntot = B * Lout;
     const int64_t gx = (Ntot + BN - 1) / BN;
     const int gy = (Cout + GBM - 1) / GBM;

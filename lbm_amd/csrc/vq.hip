@@ -71,39 +71,67 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
     const int d4 = D >> 2;  // float4 per codebook row
     for (int kbase = 0; kbase < K; kbase += kTileCodes) {
         __syncthreads();  // previous tile fully consumed
-        for (int i = threadIdx.x; i < kTileCodes * (DP / 4); i += kThreads) {
-            const int code = i / (DP / 4), c4 = i - code * (DP / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kbase + code < K && c4 < d4) v = reinterpret_cast<const float4*>(codebook + (int64_t)(kbase + code) * D)[c4];
-            *reinterpret_cast<float4*>(s_e + code * LDE + 4 * c4) = v;
+        // tile load: all loads of a group issued before the first LDS write (a rolled "load, wait, write"
+        // loop costs one L2 round trip per float4); clamped address + mask instead of a predicated load
+        constexpr int kF4 = kTileCodes * (DP / 4) / kThreads;   // float4 per thread per tile
+        constexpr int kGroup = kF4 < 8 ? kF4 : 8;
+#pragma unroll
+        for (int g0 = 0; g0 < kF4; g0 += kGroup) {
+            float4 stage[kGroup];
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const int i = threadIdx.x + (g0 + u) * kThreads;
+                const int code = i / (DP / 4), c4 = i - code * (DP / 4);
+                const bool ok = kbase + code < K && c4 < d4;
+                stage[u] = reinterpret_cast<const float4*>(codebook + (int64_t)(ok ? kbase + code : 0) * D)[ok ? c4 : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < kGroup; ++u) {
+                const int i = threadIdx.x + (g0 + u) * kThreads;
+                const int code = i / (DP / 4), c4 = i - code * (DP / 4);
+                const bool ok = kbase + code < K && c4 < d4;
+                asm volatile("" : "+v"(stage[u].x), "+v"(stage[u].y), "+v"(stage[u].z), "+v"(stage[u].w));
+                *reinterpret_cast<float4*>(s_e + code * LDE + 4 * c4) = ok ? stage[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         if (threadIdx.x < kTileCodes)
             s_ee[threadIdx.x] = (kbase + threadIdx.x < K) ? e_sqnorm[kbase + threadIdx.x] : INFINITY;
         __syncthreads();
 
+        // Both 32-code halves of the tile at once, on two independent accumulators: a single dependent
+        // chain of v_mfma_f32_32x32x2_f32 sustains only ~70 % of the issue rate (tools/probe/mfma_probe.hip,
+        // mode 3: 107 TFLOP/s; two chains: ~140).  Each chain is still the same ascending fmaf order.  Codes
+        // beyond K are zero rows with |e|^2 = +inf: their distance is +inf and never wins.
+        f32x16 acc0, acc1;
 #pragma unroll
-        for (int c = 0; c < kTileCodes / 32; ++c) {
-            if (kbase + c * 32 < K) {  // block-uniform
-                f32x16 acc;
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = 0.f;
+            acc1[r] = 0.f;
+        }
+        const float* ap0 = s_e + j * LDE + h * HALF;
+        const float* ap1 = ap0 + 32 * LDE;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const float* ap = s_e + (c * 32 + j) * LDE + h * HALF;
+        for (int q = 0; q < HALF / 4; ++q) {
+            const float4 a0 = reinterpret_cast<const float4*>(ap0)[q];
+            const float4 a1 = reinterpret_cast<const float4*>(ap1)[q];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bx[4 * q + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bx[4 * q + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bx[4 * q + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bx[4 * q + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bx[4 * q + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bx[4 * q + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bx[4 * q + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bx[4 * q + 3], acc1, 0, 0, 0);
+        }
 #pragma unroll
-                for (int q = 0; q < HALF / 4; ++q) {
-                    const float4 a = reinterpret_cast<const float4*>(ap)[q];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bx[4 * q + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bx[4 * q + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bx[4 * q + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bx[4 * q + 3], acc, 0, 0, 0);
-                }
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cl = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const float dist = (xx + s_ee[cl]) - 2.f * acc[r];
-                    if (dist < best) {
-                        best = dist;
-                        bidx = kbase + cl;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int cl = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float dist = (xx + s_ee[cl]) - 2.f * (c == 0 ? acc0[r] : acc1[r]);
+                if (dist < best) {
+                    best = dist;
+                    bidx = kbase + cl;
                 }
             }
         }
