@@ -140,10 +140,18 @@ int lbm_bandpower_f32(const float* psd, const float* freqs, float* out, int64_t 
 /* ---- a10: VQ-VAE encoder convolution ----------------------------------------------------------------
  * Replaces one nn.Conv1d(+ReLU) of VQVAE.encoder, training/model.py:169-177 (used by encode :208).
  * x: [B, Cin, Lin]; w: [Cout, Cin, ksize] (torch layout); bias: [Cout] or NULL;
- * y: [B, Cout, Lout], Lout = (Lin + 2*pad - ksize)/stride + 1.  fp32 MFMA, exact fp32 fmaf chains. */
+ * y: [B, Cout, Lout], Lout = (Lin + 2*pad - ksize)/stride + 1.  fp32 MFMA, exact fp32 fmaf chains.
+ * lbm_conv1d_pitched_f32: the same with pitched rows: channel row (b, c) of x starts at x + (b*Cin + c)*ldx,
+ * of y at y + (b*Cout + c)*ldy (ldx >= Lin, ldy >= Lout, in floats).  With 16-byte aligned x, y and pitches
+ * that are multiples of 4 every global access is a 16-byte one (the layout of the pipeline's activation
+ * buffers); the up-to-3 floats of padding at the end of a y row may then be overwritten with unspecified
+ * values.  lbm_conv1d_f32 is the dense case ldx = Lin, ldy = Lout. */
 int lbm_conv1d_f32(const float* x, const float* w, const float* bias, float* y, int64_t B, int32_t Cin,
                    int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
                    lbm_stream_t stream);
+int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                           int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride,
+                           int32_t pad, int32_t relu, lbm_stream_t stream);
 
 /* ---- a12 / a13: codebook distance + argmin ----------------------------------------------------------
  * Replaces VectorQuantizerEMA.get_code_indices, training/model.py:152-158 (same math in forward :90-95):
@@ -151,14 +159,15 @@ int lbm_conv1d_f32(const float* x, const float* w, const float* bias, float* y, 
  * The [N,K] distance matrix is never written to memory.
  * layout LBM_VQ_ROWS: x is [N, D] with row stride ldx (floats);
  * layout LBM_VQ_CHANNEL_MAJOR: x is the encoder output z[B, D, S] (N = B*S, row n = (b = n / S, s = n % S)),
- *   which removes the permute(0,2,1).contiguous() of training/model.py:209; ldx must be S.
+ *   which removes the permute(0,2,1).contiguous() of training/model.py:209; ldx >= S is the pitch of the
+ *   [b][d] rows of z (element (n, d) is x[(b*D + d)*ldx + s]).  S is ignored for LBM_VQ_ROWS.
  * codebook: [K, D]; e_sqnorm: [K] = lbm_rownorm2_f32(codebook); idx_out: [N] int64;
  * mind_or_null: [N] minimum distance; hist_or_null: [K] usage counts, ADDED to (caller zeroes).
  * D must be a multiple of 8 and <= 256; K >= 1. */
 #define LBM_VQ_ROWS 0
 #define LBM_VQ_CHANNEL_MAJOR 1
 int lbm_rownorm2_f32(const float* m, float* out, int64_t rows, int32_t D, lbm_stream_t stream);
-int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, const float* codebook,
+int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const float* codebook,
                       const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
                       unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
 

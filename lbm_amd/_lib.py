@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblbm_hip.so")
+LIB_PATH = os.environ.get("LBM_AMD_LIB") or os.path.join(_HERE, "liblbm_hip.so")   # env override: debug builds
 
 LBM_OK = 0
 PAD_REFLECT_LIMITED, PAD_ZERO = 0, 1
@@ -40,8 +40,9 @@ SIGNATURES = {
     "lbm_welch_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "lbm_bandpower_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "lbm_conv1d_pitched_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "lbm_rownorm2_f32": (C.c_int, [_p, _p, _i64, _i32, _p]),
-    "lbm_vq_argmin_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "lbm_vq_argmin_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_vq_gather_loss_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_perplexity_u64": (C.c_int, [_p, _p, _i32, _p]),
 }

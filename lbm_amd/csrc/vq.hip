@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
                                                                 const float* __restrict__ codebook,
                                                                 const float* __restrict__ e_sqnorm,
                                                                 int64_t* __restrict__ idx_out, float* __restrict__ mind,
-                                                                int64_t N, int D, int K, int vec_ok) {
+                                                                int64_t N, int D, int K, int vec_ok, int64_t S) {
     constexpr int HALF = DP / 2;
     constexpr int LDE = DP + 4;
     extern __shared__ __align__(16) float smem[];
@@ -55,11 +55,10 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
             for (int s = 0; s < HALF; ++s) bx[s] = (h * HALF + s < D) ? p[s] : 0.f;
         }
     } else {
-        const int64_t S = ldx;
-        const int64_t b = row_c / S, sp = row_c - b * S;
-        const float* p = x + (b * D + h * HALF) * S + sp;
+        const int64_t b = row_c / S, sp = row_c - b * S;   // ldx = pitch of the [b][d] rows of z, S positions per row
+        const float* p = x + (b * D + h * HALF) * ldx + sp;
 #pragma unroll
-        for (int s = 0; s < HALF; ++s) bx[s] = (h * HALF + s < D) ? p[(int64_t)s * S] : 0.f;
+        for (int s = 0; s < HALF; ++s) bx[s] = (h * HALF + s < D) ? p[(int64_t)s * ldx] : 0.f;
     }
     float xx = 0.f;
 #pragma unroll
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(256) void perplexity_kernel(const unsigned long lon
 }
 
 template <int DP>
-int launch_vq(const float* x, int64_t ldx, int layout, const float* codebook, const float* e_sqnorm, int64_t* idx_out,
+int launch_vq(const float* x, int64_t ldx, int layout, int64_t S, const float* codebook, const float* e_sqnorm, int64_t* idx_out,
               float* mind, int64_t N, int D, int K, hipStream_t st) {
     const size_t lds = ((size_t)kTileCodes * (DP + 4) + kTileCodes) * sizeof(float);
     const int64_t blocks = (N + kRowsPerBlock - 1) / kRowsPerBlock;
@@ -237,12 +236,12 @@ int launch_vq(const float* x, int64_t ldx, int layout, const float* codebook, co
         auto k = vq_argmin_kernel<DP, LBM_VQ_ROWS>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S);
     } else {
         auto k = vq_argmin_kernel<DP, LBM_VQ_CHANNEL_MAJOR>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S);
     }
     return lbm::check_launch("lbm_vq_argmin_f32");
 }
@@ -259,7 +258,7 @@ extern "C" int lbm_rownorm2_f32(const float* m, float* out, int64_t rows, int32_
     return lbm::check_launch("lbm_rownorm2_f32");
 }
 
-extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, const float* codebook,
+extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const float* codebook,
                                  const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
                                  unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream) {
     LBM_REQUIRE(N >= 0, LBM_EINVAL, "lbm_vq_argmin_f32: negative N");
@@ -272,12 +271,14 @@ extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, co
     if (layout == LBM_VQ_ROWS)
         LBM_REQUIRE(ldx >= D, LBM_EINVAL, "lbm_vq_argmin_f32: ldx (%lld) < D (%d)", (long long)ldx, D);
     else
-        LBM_REQUIRE(ldx >= 1 && N % ldx == 0, LBM_EINVAL, "lbm_vq_argmin_f32: channel-major needs N %% S == 0 (N=%lld, S=%lld)", (long long)N, (long long)ldx);
+        LBM_REQUIRE(S >= 1 && ldx >= S && N % S == 0, LBM_EINVAL,
+                    "lbm_vq_argmin_f32: channel-major needs 1 <= S <= ldx and N %% S == 0 (N=%lld, S=%lld, ldx=%lld)", (long long)N,
+                    (long long)S, (long long)ldx);
     hipStream_t st = lbm::as_stream(stream);
     int rc;
-    if (D <= 64) rc = launch_vq<64>(x, ldx, layout, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
-    else if (D <= 128) rc = launch_vq<128>(x, ldx, layout, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
-    else rc = launch_vq<256>(x, ldx, layout, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    if (D <= 64) rc = launch_vq<64>(x, ldx, layout, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else if (D <= 128) rc = launch_vq<128>(x, ldx, layout, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else rc = launch_vq<256>(x, ldx, layout, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
     if (rc != LBM_OK) return rc;
     if (hist_or_null != nullptr) {
         LBM_REQUIRE(K <= 32768, LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: histogram supports K <= 32768");

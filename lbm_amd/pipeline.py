@@ -70,6 +70,7 @@ class EpochPipeline:
             self.L1 = (T + 2 - 4) // 2 + 1
             self.L2 = (self.L1 + 2 - 4) // 2 + 1
             self.S = self.L2
+            self.P1, self.P2 = (self.L1 + 3) & ~3, (self.L2 + 3) & ~3   # row pitches of the activation buffers
         self._cap = 0
         self._buf: Dict[str, torch.Tensor] = {}
         self.stage_events = None   # set to [] to record (name, start, end) HIP events per stage on the current stream
@@ -84,7 +85,8 @@ class EpochPipeline:
              "std": mk(E, c.n_channels, c.n_times), "keep": mk(E, dt=torch.uint8),
              "psd": mk(E, c.n_channels, self.F), "bp": mk(E, 6)}
         if c.do_tokenize:
-            B.update(h1=mk(E, 64, self.L1), h2=mk(E, 128, self.L2), h3=mk(E, 256, self.L2), z=mk(E, self.D, self.L2),
+            # encoder activations: rows padded to a multiple of 4 floats, so every conv access is a 16-byte one
+            B.update(h1=mk(E, 64, self.P1), h2=mk(E, 128, self.P2), h3=mk(E, 256, self.P2), z=mk(E, self.D, self.P2),
                      tokens=mk(E, self.S, dt=torch.int64), hist=torch.zeros((self.K,), dtype=torch.int64, device=d))
         self._buf, self._cap = B, E
 
@@ -142,17 +144,18 @@ class EpochPipeline:
         out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"], "cleaned": base}
         if c.do_tokenize:
             e = self.enc
-            conv = lambda xi, yo, i, cin, lin, cout, ks, s_, pd, relu: _lib.check(  # noqa: E731
-                lib.lbm_conv1d_f32(p(xi), p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), E, cin, lin, cout, ks, s_, pd, relu, st), "conv")
-            conv(B["std"], B["h1"], 0, C, T, 64, 4, 2, 1, 1)
-            conv(B["h1"], B["h2"], 2, 64, self.L1, 128, 4, 2, 1, 1)
-            conv(B["h2"], B["h3"], 4, 128, self.L2, 256, 3, 1, 1, 1)
-            conv(B["h3"], B["z"], 6, 256, self.L2, self.D, 1, 1, 0, 0)
+            conv = lambda xi, ldx, yo, ldy, i, cin, lin, cout, ks, s_, pd, relu: _lib.check(  # noqa: E731
+                lib.lbm_conv1d_pitched_f32(p(xi), ldx, p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin,
+                                           cout, ks, s_, pd, relu, st), "conv")
+            conv(B["std"], T, B["h1"], self.P1, 0, C, T, 64, 4, 2, 1, 1)
+            conv(B["h1"], self.P1, B["h2"], self.P2, 2, 64, self.L1, 128, 4, 2, 1, 1)
+            conv(B["h2"], self.P2, B["h3"], self.P2, 4, 128, self.L2, 256, 3, 1, 1, 1)
+            conv(B["h3"], self.P2, B["z"], self.P2, 6, 256, self.L2, self.D, 1, 1, 0, 0)
             t0 = mark("encoder", t0)
-            _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.S, _lib.VQ_CHANNEL_MAJOR, p(self.codebook), p(self.ee),
+            _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.codebook), p(self.ee),
                                              p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
             t0 = mark("vq", t0)
-            out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"])
+            out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"][:, :, :self.S])
         return out
 
 

@@ -39,10 +39,11 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
     K, D = cb.shape
     if e_sqnorm is None:
         e_sqnorm = rownorm2(cb)
+    S = 0
     if channel_major:
-        x = x.contiguous()
+        x = _pitched_rows(x)
         B, Dx, S = x.shape
-        N, ldx, layout = B * S, S, _lib.VQ_CHANNEL_MAJOR
+        N, ldx, layout = B * S, (x.stride(1) if B * Dx > 1 else S), _lib.VQ_CHANNEL_MAJOR
     else:
         if x.dim() != 2:
             raise ValueError("x must be [N, D]")
@@ -56,7 +57,7 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
     mind = torch.empty((N,), dtype=torch.float32, device=x.device) if return_min else None
     if hist is not None and (hist.dtype != torch.int64 or hist.numel() != K or not hist.is_contiguous()):
         raise ValueError("hist must be a contiguous int64 tensor of K entries")
-    _lib.check(_lib.load().lbm_vq_argmin_f32(_lib.ptr(x), ldx, layout, _lib.ptr(cb), _lib.ptr(e_sqnorm), _lib.ptr(idx),
+    _lib.check(_lib.load().lbm_vq_argmin_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(cb), _lib.ptr(e_sqnorm), _lib.ptr(idx),
                                              _lib.ptr(mind), _lib.ptr(hist), N, D, K, _lib.stream_ptr()), "lbm_vq_argmin_f32")
     return (idx, mind) if return_min else idx
 
@@ -81,10 +82,31 @@ def perplexity_from_hist(hist: torch.Tensor) -> torch.Tensor:
     return out[0]
 
 
+def _pitch4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+def _pitched_rows(x: torch.Tensor) -> torch.Tensor:
+    """x[B, C, L] as the kernels address it: unit stride in L, one pitch between consecutive (b, c) rows.
+    Contiguous tensors and the [..., :L] views of pitched buffers pass through; anything else is copied."""
+    B, Cc, L = x.shape
+    if x.stride(2) == 1 and (B == 1 or x.stride(0) == Cc * x.stride(1)) and (B * Cc == 1 or x.stride(1) >= L):
+        return x
+    return x.contiguous()
+
+
+def pitched_empty(B: int, Cc: int, L: int, device) -> torch.Tensor:
+    """[B, C, L] float32 view of a buffer whose rows are padded to a multiple of 4 floats (16-byte rows)."""
+    return torch.empty((B, Cc, _pitch4(L)), dtype=torch.float32, device=device)[:, :, :L]
+
+
 def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, stride: int = 1, padding: int = 0,
-           relu: bool = False) -> torch.Tensor:
-    """nn.Conv1d (+ReLU) forward on fp32 MFMA.  x: [B, Cin, L]; weight: [Cout, Cin, k]."""
-    x = _lib.dev_f32(x)
+           relu: bool = False, pitched_out: bool = False) -> torch.Tensor:
+    """nn.Conv1d (+ReLU) forward on fp32 MFMA.  x: [B, Cin, L] (contiguous or a pitched view); weight: [Cout, Cin, k].
+    ``pitched_out`` returns a [B, Cout, Lout] view of a row-padded buffer (what the next layer reads fastest)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+        x = _lib.dev_f32(x)
+    x = _pitched_rows(x)
     w = _lib.dev_f32(weight)
     b = _lib.dev_f32(bias) if bias is not None else None
     B, Cin, Lin = x.shape
@@ -92,22 +114,25 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, str
     if Cin_w != Cin:
         raise ValueError(f"weight expects {Cin_w} input channels, got {Cin}")
     Lout = (Lin + 2 * padding - ks) // stride + 1
-    y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().lbm_conv1d_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), B, Cin, Lin, Cout, ks, stride,
-                                          padding, int(relu), _lib.stream_ptr()), "lbm_conv1d_f32")
+    y = pitched_empty(B, Cout, Lout, x.device) if pitched_out else torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
+    ldx = x.stride(1) if B * Cin > 1 else Lin
+    ldy = y.stride(1) if B * Cout > 1 else Lout
+    _lib.check(_lib.load().lbm_conv1d_pitched_f32(_lib.ptr(x), ldx, _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), ldy, B, Cin, Lin, Cout,
+                                                  ks, stride, padding, int(relu), _lib.stream_ptr()), "lbm_conv1d_pitched_f32")
     return y
 
 
-def encoder_forward(x: torch.Tensor, enc: "nn.Sequential | dict") -> torch.Tensor:
-    """VQVAE.encoder (training/model.py:169-177) on the HIP conv kernel: [B, C, L] -> [B, D, L//4]."""
+def encoder_forward(x: torch.Tensor, enc: "nn.Sequential | dict", pitched_out: bool = False) -> torch.Tensor:
+    """VQVAE.encoder (training/model.py:169-177) on the HIP conv kernel: [B, C, L] -> [B, D, L//4].
+    Intermediate activations live in row-padded buffers (16-byte rows)."""
     if isinstance(enc, dict):
         g = lambda i, n: enc[f"encoder.{i}.{n}"]  # noqa: E731
     else:
         g = lambda i, n: getattr(enc[i], n)  # noqa: E731
-    z = conv1d(x, g(0, "weight"), g(0, "bias"), 2, 1, True)
-    z = conv1d(z, g(2, "weight"), g(2, "bias"), 2, 1, True)
-    z = conv1d(z, g(4, "weight"), g(4, "bias"), 1, 1, True)
-    return conv1d(z, g(6, "weight"), g(6, "bias"), 1, 0, False)
+    z = conv1d(x, g(0, "weight"), g(0, "bias"), 2, 1, True, pitched_out=True)
+    z = conv1d(z, g(2, "weight"), g(2, "bias"), 2, 1, True, pitched_out=True)
+    z = conv1d(z, g(4, "weight"), g(4, "bias"), 1, 1, True, pitched_out=True)
+    return conv1d(z, g(6, "weight"), g(6, "bias"), 1, 0, False, pitched_out=pitched_out)
 
 
 # ------------------------------------------------------------------------------------------ modules
@@ -207,7 +232,7 @@ class VQVAE(nn.Module):
     def encode(self, x, hist=None):
         """Input x[B, C, L] -> code indices int64 [B, L//4] (training/model.py:206-214), all on HIP kernels;
         the encoder output is consumed channel-major, so the permute(0,2,1).contiguous() copy disappears."""
-        z = encoder_forward(x, self.encoder)
+        z = encoder_forward(x, self.encoder, pitched_out=True)
         idx = self.vq_layer.get_code_indices_channel_major(z, hist=hist)
         return idx.view(x.shape[0], -1)
 

@@ -247,6 +247,26 @@ def test_conv1d_matches_torch_cpu(B, Cin, L, Cout, k, s, p):
         assert float((y.double() - want).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 30, 1500, 64, 4, 2, 1), (2, 64, 750, 128, 4, 2, 1), (2, 128, 375, 256, 3, 1, 1),
+                                                (2, 256, 375, 256, 1, 1, 0), (2, 12, 130, 40, 3, 1, 1), (1, 20, 9, 7, 1, 1, 0)])
+def test_conv1d_pitched_rows_bitwise_equal_dense(B, Cin, L, Cout, k, s, p):
+    """Row-padded (16-byte) activation buffers in and out give bit-identical results to dense tensors."""
+    from lbm_amd.quantizer import pitched_empty
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, Cin, L, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    dense = lbm_amd.conv1d(x, w, b, s, p, True)
+    xp = pitched_empty(B, Cin, L, DEV)
+    xp.copy_(x)
+    xp.as_strided((B, Cin, xp.stride(1)), xp.stride())[:, :, L:] = float("nan")     # the padding must never be read as data
+    yp = lbm_amd.conv1d(xp, w, b, s, p, True, pitched_out=True)
+    assert yp.shape == dense.shape and yp.stride(1) % 4 == 0
+    assert torch.equal(yp, dense)
+    want = torch.relu(torch.nn.functional.conv1d(x.double().cpu(), w.double().cpu(), b.double().cpu(), stride=s, padding=p))
+    assert float((dense.double().cpu() - want).abs().max()) <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ a12-a14 VQ
 def test_vq_golden_get_code_indices(shipped, vq_golden):
     cb = shipped["vq_layer.embedding.weight"]
@@ -289,6 +309,9 @@ def test_vq_random_codebooks_match_oracle(N, D, K):
         S = N // 5
         z = torch.from_numpy(x).to(DEV).view(5, S, D).permute(0, 2, 1).contiguous()   # [B, D, S]
         assert np.array_equal(lbm_amd.vq_argmin(z, torch.from_numpy(cb).to(DEV), channel_major=True).cpu().numpy(), idx)
+        zp = torch.full((5, D, S + 3), float("nan"), device=DEV)                      # pitched rows, padding never read
+        zp[:, :, :S] = z
+        assert np.array_equal(lbm_amd.vq_argmin(zp[:, :, :S], torch.from_numpy(cb).to(DEV), channel_major=True).cpu().numpy(), idx)
 
 
 def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):

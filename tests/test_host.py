@@ -104,7 +104,7 @@ def test_argument_validation_without_launch():
     assert lib.lbm_fir_f32(None, None, 4, 100, None, 5, 0, None) == -1
     assert b"NULL" in lib.lbm_last_error()
     assert lib.lbm_fir_f32(None, None, 0, 100, None, 4, 0, None) == 0          # empty input is a no-op
-    assert lib.lbm_vq_argmin_f32(None, 256, 0, None, None, None, None, None, 10, 100, 512, None) == -2   # D % 8 != 0
+    assert lib.lbm_vq_argmin_f32(None, 256, 0, 0, None, None, None, None, None, 10, 100, 512, None) == -2   # D % 8 != 0
     assert lib.lbm_welch_f32(None, None, None, 10, 100, 500.0, 500, 500, 250, None, 4, 30, 0, None) == -1  # nfft > T
     assert b"larger than the number of samples" in lib.lbm_last_error()
     assert lib.lbm_welch_tables_bytes(500, 500, 4, 30) >= 64 + 4 * 1500

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--stage", required=True)
     ap.add_argument("--epochs", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dense", action="store_true", help="conv stages: dense rows (pitch = length) instead of 16-byte rows")
+    ap.add_argument("--cin", type=int, default=0, help="conv stages: override the input channel count (random weights)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -38,21 +40,26 @@ def main():
         x = synth_epochs(E, C, T, seed=3, device=dev, chunk=2048)
         y = torch.empty_like(x)
     if s == "vq":
-        z = rnd(E, 256, S)
+        PS = (S + 3) & ~3
+        z = rnd(E, 256, PS)
         cb = w["vq_layer.embedding.weight"].contiguous()
         ee = torch.empty(512, device=dev)
         lib.lbm_rownorm2_f32(p(cb), p(ee), 512, 256, st)
         tok = torch.empty(E, S, dtype=torch.int64, device=dev)
-        fn = lambda: lib.lbm_vq_argmin_f32(p(z), S, _lib.VQ_CHANNEL_MAJOR, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
+        fn = lambda: lib.lbm_vq_argmin_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
     elif s.startswith("conv"):
         i = int(s[4]) - 1
         cin, lin, cout, ks, sd, pd, relu = [(30, 1500, 64, 4, 2, 1, 1), (64, 750, 128, 4, 2, 1, 1), (128, 375, 256, 3, 1, 1, 1),
                                             (256, 375, 256, 1, 1, 0, 0)][i]
-        xin = rnd(E, cin, lin)
-        lout = (lin + 2 * pd - ks) // sd + 1
-        yo = torch.empty(E, cout, lout, device=dev)
         wt, bs = w[f"encoder.{2 * i}.weight"].contiguous(), w[f"encoder.{2 * i}.bias"].contiguous()
-        fn = lambda: lib.lbm_conv1d_f32(p(xin), p(wt), p(bs), p(yo), E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
+        if args.cin:
+            cin = args.cin
+            wt = rnd(cout, cin, ks) * 0.05
+        lout = (lin + 2 * pd - ks) // sd + 1
+        ldx, ldy = ((lin + 3) & ~3, (lout + 3) & ~3) if not args.dense else (lin, lout)
+        xin = rnd(E, cin, ldx)
+        yo = torch.empty(E, cout, ldy, device=dev)
+        fn = lambda: lib.lbm_conv1d_pitched_f32(p(xin), ldx, p(wt), p(bs), p(yo), ldy, E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
     elif s in ("fir", "fir_direct"):
         taps = torch.as_tensor(lbm_amd.create_filter(500.0, 4.0, 30.0)).to(dev, torch.float32)
         if s == "fir":
@@ -86,7 +93,11 @@ def main():
         fn()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{s}: {e0.elapsed_time(e1) / args.reps:.4f} ms per launch ({E} epochs)")
+    ms = e0.elapsed_time(e1) / args.reps
+    extra = ""
+    if s.startswith("conv"):
+        extra = f", {2.0 * cout * cin * ks * lout * E / (ms * 1e-3) / 1e12:.1f} TFLOP/s"
+    print(f"{s}: {ms:.4f} ms per launch ({E} epochs{extra})")
 
 
 if __name__ == "__main__":
