@@ -4,10 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the whole hot path (FIR band-pass -> ICA affine -> baseline/reject/z-score ->
-Welch PSD -> band powers -> VQ-VAE encoder -> codebook argmin + usage histogram) over one resident chunk
-of synthetic 30-channel x 500 Hz x 3 s fp32 epochs (BASELINE.json config 3, streamed in chunks).
-For N > 1 (torchrun, one rank per GPU) every rank processes its own chunk (weak scaling, epochs shard
-trivially); the only collectives of the path -- all-gather of the token array and all-reduce of the
+Welch PSD -> band powers -> VQ-VAE encoder -> codebook argmin + usage histogram) over BASELINE.json
+config 3: 1 000 000 synthetic 30-channel x 500 Hz x 3 s fp32 epochs per GPU, RESIDENT in HBM (180 GB) before
+the timed region, walked in chunks of 16 384 epochs (the pipeline's stage buffers are sized for one chunk).
+Per-epoch outputs (tokens, PSD, band features, keep mask) are kept for the whole job.
+For N > 1 (torchrun, one rank per GPU) every rank processes its own 1 M epochs (weak scaling: config 4, epochs
+shard trivially); the only collectives of the path -- all-gather of the token array and all-reduce of the
 codebook usage histogram -- run once per step inside the timed region.
 Prints ONE JSON line on rank 0.
 """
@@ -24,23 +26,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import lbm_amd  # noqa: E402
-from lbm_amd.synth import synth_codebook, synth_encoder, synth_epochs, synth_ica  # noqa: E402
+from lbm_amd.synth import synth_codebook, synth_epochs, synth_ica  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
+KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_fold_kernel",
+                   "bandpower": "bandpower_kernel", "conv1": "conv_tile_kernel<4,2,64>", "conv2": "conv_tile_kernel<4,2,128>",
+                   "conv3": "conv_tile_kernel<3,1,128>", "conv4": "conv_tile_kernel<1,1,128>", "vq": "vq_argmin_kernel"}
 
 
-def stage_model(E, C, T, ntaps, K, D, S, L1, F):
-    """Algorithmic flops / bytes per step of each stage (SURVEY.md 8d figures x epochs in the chunk)."""
+def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048):
+    """Algorithmic flops / compulsory HBM bytes per launch of each stage over E epochs (SURVEY.md 8d figures)."""
     ep = C * T * 4
-    enc_flops = 2 * (64 * C * 4 * L1 + 128 * 64 * 4 * S + 256 * 128 * 3 * S + D * 256 * S)
+    fft_flops = 2 * 5.0 * fft_n * np.log2(fft_n) + 6.0 * fft_n       # forward + inverse complex FFT + spectrum product, per row
     return {
-        "fir": dict(flops=2.0 * ntaps * C * T * E, bytes=2.0 * ep * E, bound="mfma"),
+        "fir": dict(flops=fft_flops * C * E, direct_flops=2.0 * ntaps * C * T * E, bytes=2.0 * ep * E, bound="hbm"),
         "affine": dict(flops=2.0 * C * C * T * E, bytes=2.0 * ep * E, bound="hbm"),
         "post": dict(flops=8.0 * C * T * E, bytes=3.0 * ep * E, bound="hbm"),
         "welch": dict(flops=2.0e6 * E * (C * T / 45000.0), bytes=(ep + C * F * 4) * E, bound="hbm"),
         "bandpower": dict(flops=0.0, bytes=(C * F * 4 + 24) * E, bound="hbm"),
-        "encoder": dict(flops=float(enc_flops) * E, bytes=(ep + D * S * 4) * E, bound="mfma"),
+        "conv1": dict(flops=2.0 * 64 * C * 4 * L1 * E, bytes=(ep + 64 * L1 * 4) * E, bound="mfma"),
+        "conv2": dict(flops=2.0 * 128 * 64 * 4 * S * E, bytes=(64 * L1 * 4 + 128 * S * 4) * E, bound="mfma"),
+        "conv3": dict(flops=2.0 * 256 * 128 * 3 * S * E, bytes=(128 * S * 4 + 256 * S * 4) * E, bound="mfma"),
+        "conv4": dict(flops=2.0 * D * 256 * S * E, bytes=(256 * S * 4 + D * S * 4) * E, bound="mfma"),
         "vq": dict(flops=2.0 * S * K * D * E, bytes=(D * S * 4 + S * 8) * E, bound="mfma"),
     }
 
@@ -53,21 +61,32 @@ def cpu_baseline(taps, A, b, weights, sample_epochs):
     torch.set_num_threads(cores)
     x = synth_epochs(sample_epochs, 30, 1500, seed=99).numpy()
     t0 = time.perf_counter()
-    orc.pipeline(x, 500.0, taps, A, b, 251, 150e-6, weights, fft_filter=True)
+    for lo in range(0, sample_epochs, 256):
+        orc.pipeline(x[lo:lo + 256], 500.0, taps, A, b, 251, 150e-6, weights, fft_filter=True)
     dt = time.perf_counter() - t0
-    return {"value": sample_epochs / dt, "unit": "epochs/s", "cores": cores, "kind": "port",
+    return {"value": round(sample_epochs / dt, 1), "unit": "epochs/s", "cores": cores, "kind": "port",
             "sample": f"{sample_epochs} synthetic 30x1500 epochs through oracle/eeg_oracle.pipeline "
                       f"(float64 scipy FIR(oaconvolve)/ICA/Welch + torch-CPU fp32 encoder+VQ), {dt:.1f} s"}
+
+
+def alloc_resident(E, C, T, dev, reserve_bytes):
+    """[R, C, T] input with R = E if it fits next to `reserve_bytes` of other buffers, else the largest halving that does."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    R = E
+    while R > 1 and R * C * T * 4 + reserve_bytes > free:
+        R = (R + 1) // 2
+    return torch.empty((R, C, T), dtype=torch.float32, device=dev)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunk", type=int, default=16384, help="epochs per step per GPU")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--epochs", type=int, default=1_000_000, help="epochs per step per GPU (BASELINE config 3: 1M)")
+    ap.add_argument("--chunk", type=int, default=16384, help="epochs per pipeline launch")
     ap.add_argument("--codebook", type=int, default=512)
-    ap.add_argument("--cpu-sample", type=int, default=256, help="epochs for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
@@ -83,26 +102,46 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     C, T, fs, K, D = 30, 1500, 500.0, args.codebook, 256
+    E, chunk = args.epochs, min(args.chunk, args.epochs)
     taps = lbm_amd.create_filter(fs, 4.0, 30.0)
     A, b = lbm_amd.ica_projection(**synth_ica(C))
-    shipped_path = os.path.join(ROOT, "tests", "golden", "vq_vae_shipped.npz")
-    with np.load(shipped_path) as f:
+    with np.load(os.path.join(ROOT, "tests", "golden", "vq_vae_shipped.npz")) as f:
         weights = {k: f[k] for k in f.files}          # shipped encoder (C = 30)
     codebook = weights["vq_layer.embedding.weight"] if K == 512 else synth_codebook(K, D)
     cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=251)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
+    pipe._reserve(chunk)
+    S, F = pipe.S, pipe.F
 
-    E = args.chunk
-    x = synth_epochs(E, C, T, sfreq=fs, seed=lbm_amd.synth.SEED + rank, device=dev, chunk=2048)
-    tok_all = torch.empty((world * E, pipe.S), dtype=torch.int64, device=dev) if world > 1 else None
+    # job-level outputs and the resident input
+    tok_dtype = torch.int16 if K < 32768 else torch.int32     # wire/storage width of the tokens; int64 at the API
+    tokens = torch.empty((E, S), dtype=tok_dtype, device=dev)
+    psd = torch.empty((E, C, F), dtype=torch.float32, device=dev)
+    bp = torch.empty((E, 6), dtype=torch.float32, device=dev)
+    keep = torch.empty((E,), dtype=torch.uint8, device=dev)
+    gathered = torch.empty((world * E, S), dtype=tok_dtype, device=dev) if (world > 1 and not args.no_gather) else None
+    x = alloc_resident(E, C, T, dev, reserve_bytes=6 << 30)
+    R = x.shape[0]
+    synth_epochs(R, C, T, sfreq=fs, seed=lbm_amd.synth.SEED + rank, device=dev, chunk=2048, out=x)
+    torch.cuda.synchronize()
 
     def step():
         pipe.reset_hist()
-        out = pipe.run(x)
-        if world > 1 and not args.no_gather:
-            dist.all_gather_into_tensor(tok_all, out["tokens"])
-            dist.all_reduce(out["hist"])
-        return out
+        for lo in range(0, E, chunk):
+            n = min(chunk, E - lo)
+            src = lo % R
+            if src + n > R:
+                src = R - n
+            out = pipe.run(x[src:src + n])
+            tokens[lo:lo + n].copy_(out["tokens"])
+            psd[lo:lo + n].copy_(out["psd"])
+            bp[lo:lo + n].copy_(out["bandpower"])
+            keep[lo:lo + n].copy_(out["keep"])
+        hist = pipe._buf["hist"]
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, tokens)
+            dist.all_reduce(hist)
+        return hist
 
     for _ in range(args.warmup):
         step()
@@ -123,36 +162,41 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # per-stage durations from HIP events recorded on the launch stream (outside the timed region)
+    # per-kernel durations from HIP events recorded on the launch stream (one chunk, outside the timed region)
     stages = {}
     if rank == 0:
-        reps = max(3, min(args.steps, 10))
+        reps = 5
         pipe.stage_events = []
         for _ in range(reps):
             pipe.reset_hist()
-            pipe.run(x)
+            pipe.run(x[:chunk])
         torch.cuda.synchronize()
         acc = {}
         for name, s_, e_ in pipe.stage_events:
             acc.setdefault(name, []).append(s_.elapsed_time(e_))
         pipe.stage_events = None
-        model = stage_model(E, C, T, len(taps), K, D, pipe.S, pipe.L1, pipe.F)
+        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F)
         for name, ms in acc.items():
             m = float(np.mean(ms))
-            st = {"ms": round(m, 4), "bound": model[name]["bound"],
-                  "tflops": round(model[name]["flops"] / (m * 1e-3) / 1e12, 3),
-                  "gbs": round(model[name]["bytes"] / (m * 1e-3) / 1e9, 1)}
-            stages[name] = st
+            stages[name] = {"ms": round(m, 4), "bound": model[name]["bound"],
+                            "tflops": round(model[name]["flops"] / (m * 1e-3) / 1e12, 3),
+                            "gbs": round(model[name]["bytes"] / (m * 1e-3) / 1e9, 1)}
 
     if rank == 0:
-        dom = max(stages, key=lambda k: stages[k]["ms"])
-        m = stage_model(E, C, T, len(taps), K, D, pipe.S, pipe.L1, pipe.F)[dom]
+        dom = max(stages, key=lambda k: stages[k]["ms"])      # the dominant single kernel of a chunk
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+        m = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F)[dom]
         if m["bound"] == "mfma":
-            roof = {"kernel": dom, "bound": "mfma", "achieved": stages[dom]["tflops"], "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(stages[dom]["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": None}
+            roof = {"kernel": KERNEL_OF_STAGE[dom], "bound": "mfma", "achieved": stages[dom]["tflops"], "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(stages[dom]["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic}
         else:
-            roof = {"kernel": dom, "bound": "hbm", "achieved": stages[dom]["gbs"], "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(stages[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": None}
+            roof = {"kernel": KERNEL_OF_STAGE[dom], "bound": "hbm", "achieved": stages[dom]["gbs"], "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(stages[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}
+        roof["launch"] = f"{chunk} epochs, {stages[dom]['ms']} ms"
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(taps, A, b, weights, args.cpu_sample)
@@ -166,9 +210,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "config3: full pipeline (825-tap FIR + ICA affine + baseline/reject/z-score + Welch PSD "
                                    "+ band power + VQ-VAE encoder + K=%d codebook argmin), 30ch x 500Hz x 3s fp32 epochs, "
-                                   "%d epochs per step per GPU, inputs resident in HBM" % (K, E),
-                       "epochs_per_step_per_gpu": E, "channels": C, "samples": T, "codebook": K,
-                       "collectives": "all_gather(tokens)+all_reduce(hist)" if (world > 1 and not args.no_gather) else "none"},
+                                   "%d epochs per step per GPU resident in HBM, walked in chunks of %d" % (K, E, chunk),
+                       "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
+                       "codebook": K,
+                       "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "stages": stages,

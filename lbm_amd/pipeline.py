@@ -148,10 +148,13 @@ class EpochPipeline:
                 lib.lbm_conv1d_pitched_f32(p(xi), ldx, p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin,
                                            cout, ks, s_, pd, relu, st), "conv")
             conv(B["std"], T, B["h1"], self.P1, 0, C, T, 64, 4, 2, 1, 1)
+            t0 = mark("conv1", t0)
             conv(B["h1"], self.P1, B["h2"], self.P2, 2, 64, self.L1, 128, 4, 2, 1, 1)
+            t0 = mark("conv2", t0)
             conv(B["h2"], self.P2, B["h3"], self.P2, 4, 128, self.L2, 256, 3, 1, 1, 1)
+            t0 = mark("conv3", t0)
             conv(B["h3"], self.P2, B["z"], self.P2, 6, 256, self.L2, self.D, 1, 1, 0, 0)
-            t0 = mark("encoder", t0)
+            t0 = mark("conv4", t0)
             _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.codebook), p(self.ee),
                                              p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
             t0 = mark("vq", t0)

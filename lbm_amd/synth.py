@@ -15,9 +15,11 @@ SEED = 20250620
 
 
 def synth_epochs(E: int, C: int = 30, T: int = 1500, sfreq: float = 500.0, seed: int = SEED, device="cpu",
-                 chunk: int = 4096) -> torch.Tensor:
+                 chunk: int = 4096, out: torch.Tensor = None) -> torch.Tensor:
+    """``out`` ([E, C, T] float32 on ``device``) is filled in place when given (large resident benchmark inputs)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    out = torch.empty((E, C, T), dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty((E, C, T), dtype=torch.float32, device=device)
     t = torch.arange(T, dtype=torch.float32, device=device) / sfreq
     ramp = torch.linspace(0.0, 1.0, T, device=device)
     for e0 in range(0, E, chunk):

@@ -11,15 +11,16 @@ dev = torch.device("cuda", 0)
 E = 4096
 cfgs = {"conv4": (256, 375, 256, 1, 1, 0), "conv3": (128, 375, 256, 3, 1, 1), "conv2": (64, 750, 128, 4, 2, 1), "conv1": (30, 1500, 64, 4, 2, 1)}
 for name, (cin, lin, cout, ks, sd, pd) in cfgs.items():
-    x = torch.randn(E, cin, lin, device=dev); w = torch.randn(cout, cin, ks, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     lout = (lin + 2 * pd - ks) // sd + 1
-    y = torch.empty(E, cout, lout, device=dev)
+    ldx, ldy = (lin + 3) & ~3, (lout + 3) & ~3
+    x = torch.randn(E, cin, ldx, device=dev); w = torch.randn(cout, cin, ks, device=dev) * 0.05; b = torch.randn(cout, device=dev)
+    y = torch.empty(E, cout, ldy, device=dev)
     bm = 64 if cout <= 64 else 128
     nblk = E * ((lout + 127) // 128) * ((cout + bm - 1) // bm)
     st = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
     for rep in range(2):
         lib.lbm_debug_stamps(st.data_ptr())
-        rc = lib.lbm_conv1d_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), E, cin, lin, cout, ks, sd, pd, 1, None)
+        rc = lib.lbm_conv1d_pitched_f32(x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), y.data_ptr(), ldy, E, cin, lin, cout, ks, sd, pd, 1, None)
         torch.cuda.synchronize()
     s = st.cpu().numpy().reshape(-1, 4).astype(np.float64)
     d = np.diff(s, axis=1)
