@@ -169,8 +169,24 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
             const float* src = x + row0 * (int64_t)T;
             const int nfl = nrows * T;
             if ((((uintptr_t)src) & 15) == 0) {
+                // batches of 8 loads in flight per lane: a rolled "load, wait, write" loop pays one HBM round
+                // trip per float4 (18 per group at 3 rows x 1500 samples)
                 const int n4 = nfl >> 2;
-                for (int i = lane; i < n4; i += 64) reinterpret_cast<float4*>(s_rows)[i] = reinterpret_cast<const float4*>(src)[i];
+                const float4* src4 = reinterpret_cast<const float4*>(src);
+                for (int i0 = 0; i0 < n4; i0 += 64 * 8) {
+                    float4 st[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = i0 + u * 64 + lane;
+                        st[u] = src4[idx < n4 ? idx : n4 - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int idx = i0 + u * 64 + lane;
+                        asm volatile("" : "+v"(st[u].x), "+v"(st[u].y), "+v"(st[u].z), "+v"(st[u].w));
+                        if (idx < n4) reinterpret_cast<float4*>(s_rows)[idx] = st[u];
+                    }
+                }
                 for (int i = (n4 << 2) + lane; i < nfl; i += 64) s_rows[i] = src[i];
             } else {
                 for (int i = lane; i < nfl; i += 64) s_rows[i] = src[i];
