@@ -139,7 +139,7 @@ def main():
             keep[lo:lo + n].copy_(out["keep"])
         hist = pipe._buf["hist"]
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, tokens)
+            dist.all_gather_into_tensor(gathered.view(torch.uint8), tokens.view(torch.uint8))   # RCCL has no int16: bytes
             dist.all_reduce(hist)
         return hist
 

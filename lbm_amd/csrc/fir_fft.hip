@@ -47,14 +47,18 @@ bool make_plan(int T, int ntaps, FftPlan* out) {
     return found;
 }
 
-// Sample m of the padded row, branch-free: ONE unconditional load at a clamped index, then selects (a
-// "load or zero" conditional would make the compiler branch around each of the 32 loads and drain vmcnt).
-__device__ __forceinline__ float padded_sample(const float* __restrict__ xr, int m, int T, bool reflect, float x0,
-                                               float xl, bool live) {
+// Sample m of the padded row in two halves, so that the global load can be issued one item ahead:
+// padded_index gives the (always valid) element to load, padded_value turns the loaded element into the
+// padded sample with selects only.  No load sits under a condition (a "load or zero" conditional would make
+// the compiler branch around each of the 32 loads and drain vmcnt).
+__device__ __forceinline__ int padded_index(int m, int T) {
+    const int idx = m < 0 ? -m : (m >= T ? 2 * (T - 1) - m : m);
+    return (idx >= 0 && idx < T) ? idx : 0;
+}
+__device__ __forceinline__ float padded_value(float v, int m, int T, bool reflect, float x0, float xl, bool live) {
     const bool left = m < 0, right = m >= T;
     const int idx = left ? -m : (right ? 2 * (T - 1) - m : m);
     const bool ok = idx >= 0 && idx < T;
-    const float v = xr[ok ? idx : 0];
     const float refl = 2.f * (left ? x0 : xl) - v;
     const float out = (left || right) ? (reflect ? refl : 0.f) : v;
     return (ok && live) ? out : 0.f;
@@ -122,21 +126,47 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
     const int seg = Lb + ntaps - 1;      // input samples a block needs (<= N)
     const int k1 = t / R3, n3 = t % R3;  // stage-2 role of this thread
 
-    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    // raw samples of the NEXT item, loaded while the current one is transformed
+    float nre[16], nim[16], nx0, nxl;
+    auto prefetch = [&](long long item) {
         const long long row = item / npairs;
         const int pair = (int)(item % npairs);
         const float* xr = x + row * (long long)T;
         const int a0 = 2 * pair * Lb, b0 = a0 + Lb;
-        const float x0 = xr[0], xl = xr[T - 1];
-        const bool has_a = a0 < T, has_b = b0 < T;
-
-        float re[16], im[16];
+        nx0 = xr[0];
+        nxl = xr[T - 1];
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int p = t + Q * n1;
-            const bool in = p < seg;
-            re[n1] = padded_sample(xr, a0 - half + p, T, reflect, x0, xl, in && has_a);
-            im[n1] = padded_sample(xr, b0 - half + p, T, reflect, x0, xl, in && has_b);
+            nre[n1] = xr[padded_index(a0 - half + p, T)];
+            nim[n1] = xr[padded_index(b0 - half + p, T)];
+        }
+    };
+    if ((long long)blockIdx.x < items) prefetch(blockIdx.x);
+
+    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+        const long long row = item / npairs;
+        const int pair = (int)(item % npairs);
+        const int a0 = 2 * pair * Lb, b0 = a0 + Lb;
+        const bool has_a = a0 < T, has_b = b0 < T;
+
+        float re[16], im[16];
+        {
+            float x0 = nx0, xl = nxl;
+            asm volatile("" : "+v"(x0), "+v"(xl));
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int p = t + Q * n1;
+                const bool in = p < seg;
+                float vr = nre[n1], vi = nim[n1];
+                asm volatile("" : "+v"(vr), "+v"(vi));   // pins the loads: none may sink under a select
+                re[n1] = padded_value(vr, a0 - half + p, T, reflect, x0, xl, in && has_a);
+                im[n1] = padded_value(vi, b0 - half + p, T, reflect, x0, xl, in && has_b);
+            }
+        }
+        {   // next item's loads fly under this item's transforms (the last item re-reads itself, unused)
+            const long long nxt = item + gridDim.x;
+            prefetch(nxt < items ? nxt : item);
         }
 
         // ---- forward stage 1
