@@ -382,6 +382,8 @@ extern "C" int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* 
     if (w_vec && Cin >= ck && pad <= (ksize == 1 ? 0 : 4)) {
         if (ksize == 4 && stride == 2 && Cout <= 64) return launch_tile<4, 2, 64>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 4 && stride == 2) return launch_tile<4, 2, 128>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
+        if (ksize == 3 && stride == 1 && Cin % 4 == 0 && Cout >= 256) return launch_tile<3, 1, 256>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
+        if (ksize == 1 && stride == 1 && Cout >= 256) return launch_tile<1, 1, 256>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 3 && stride == 1 && Cin % 4 == 0) return launch_tile<3, 1, 128>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 1 && stride == 1) return launch_tile<1, 1, 128>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
     }

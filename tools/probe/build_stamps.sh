@@ -12,12 +12,12 @@ def rep(a,b):
     assert a in s, a
     s=s.replace(a,b,1)
 rep('namespace {\n\nusing f32x16','__device__ unsigned long long* g_stamps = nullptr;\nextern "C" int lbm_debug_stamps(unsigned long long* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }\n\nnamespace {\n\nusing f32x16')
-rep('    extern __shared__ __align__(16) float smem[];\n    float* const s_a0 = smem;','    const unsigned long long T0 = __builtin_amdgcn_s_memtime();\n    extern __shared__ __align__(16) float smem[];\n    float* const s_a0 = smem;')
+rep('    extern __shared__ __align__(16) float smem[];\n    float* const s_a0 = smem;','    const unsigned long long T0 = __builtin_amdgcn_s_memtime();\n    const unsigned long long R0 = __builtin_amdgcn_s_memrealtime();\n    extern __shared__ __align__(16) float smem[];\n    float* const s_a0 = smem;')
 rep('    store_chunk(0, 0);\n    __syncthreads();\n','    store_chunk(0, 0);\n    __syncthreads();\n    const unsigned long long T1 = __builtin_amdgcn_s_memtime();\n')
 rep('    mfma_block((nchunks - 1) & 1, 0, QN);\n','    mfma_block((nchunks - 1) & 1, 0, QN);\n    asm volatile("" : "+v"(acc[0][0][0]));\n    const unsigned long long T2 = __builtin_amdgcn_s_memtime();\n')
 idx=s.index('// ---------------------------------------------------------------------------------------------- generic path')
 k=s.rfind('}\n',0,idx)
-s=s[:k]+'    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    const unsigned long long T3 = __builtin_amdgcn_s_memtime();\n    if (g_stamps != nullptr && threadIdx.x == 0) {\n        unsigned long long* q = g_stamps + 4 * (size_t)blockIdx.x;\n        q[0] = T0; q[1] = T1; q[2] = T2; q[3] = T3;\n    }\n'+s[k:]
+s=s[:k]+'    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n    const unsigned long long T3 = __builtin_amdgcn_s_memtime();\n    if (g_stamps != nullptr && threadIdx.x == 0) {\n        unsigned long long* q = g_stamps + 4 * (size_t)blockIdx.x;\n        q[0] = T0; q[1] = T1; q[2] = T2; q[3] = T3;\n        if (blockIdx.x & 1) { q[1] = R0; q[2] = __builtin_amdgcn_s_memrealtime(); }\n    }\n'+s[k:]
 open(p,'w').write(s)
 PY
 cd $W

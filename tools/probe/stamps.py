@@ -15,7 +15,7 @@ for name, (cin, lin, cout, ks, sd, pd) in cfgs.items():
     ldx, ldy = (lin + 3) & ~3, (lout + 3) & ~3
     x = torch.randn(E, cin, ldx, device=dev); w = torch.randn(cout, cin, ks, device=dev) * 0.05; b = torch.randn(cout, device=dev)
     y = torch.empty(E, cout, ldy, device=dev)
-    bm = 64 if cout <= 64 else 128
+    bm = 64 if cout <= 64 else (256 if (cout >= 256 and ks in (1, 3)) else 128)
     nblk = E * ((lout + 127) // 128) * ((cout + bm - 1) // bm)
     st = torch.zeros(nblk * 4, dtype=torch.int64, device=dev)
     for rep in range(2):
@@ -23,6 +23,10 @@ for name, (cin, lin, cout, ks, sd, pd) in cfgs.items():
         rc = lib.lbm_conv1d_pitched_f32(x.data_ptr(), ldx, w.data_ptr(), b.data_ptr(), y.data_ptr(), ldy, E, cin, lin, cout, ks, sd, pd, 1, None)
         torch.cuda.synchronize()
     s = st.cpu().numpy().reshape(-1, 4).astype(np.float64)
+    odd = s[1::2]   # odd blocks carry (memtime T0, realtime R0, realtime R3, memtime T3)
+    clk = (odd[:, 3] - odd[:, 0]) / np.maximum(odd[:, 2] - odd[:, 1], 1) * 100e6
+    print(f"{name}: in-kernel clock median {np.median(clk) / 1e9:.3f} GHz (p10 {np.percentile(clk, 10) / 1e9:.3f}, p90 {np.percentile(clk, 90) / 1e9:.3f})")
+    s = s[0::2]
     d = np.diff(s, axis=1)
     ok = (d > 0).all(axis=1) & (d < 1e7).all(axis=1)
     d = d[ok]
