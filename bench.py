@@ -88,7 +88,17 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--shape", choices=["S", "L"], default="S",
+                    help="S = 30ch x 500Hz x 3s, K=512 (configs 3/4, the metric's workload); L = 64ch x 1kHz x 10s, "
+                         "K=8192, 16384 epochs (config 5, for measurement only)")
     args = ap.parse_args()
+    if args.shape == "L":
+        if args.epochs == 1_000_000:
+            args.epochs = 16384
+        if args.codebook == 512:
+            args.codebook = 8192
+        args.chunk = min(args.chunk, 1024)
+        args.cpu_sample = 0
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,14 +111,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    C, T, fs, K, D = 30, 1500, 500.0, args.codebook, 256
+    C, T, fs, K, D = (30, 1500, 500.0, args.codebook, 256) if args.shape == "S" else (64, 10000, 1000.0, args.codebook, 256)
     E, chunk = args.epochs, min(args.chunk, args.epochs)
     taps = lbm_amd.create_filter(fs, 4.0, 30.0)
     A, b = lbm_amd.ica_projection(**synth_ica(C))
-    with np.load(os.path.join(ROOT, "tests", "golden", "vq_vae_shipped.npz")) as f:
-        weights = {k: f[k] for k in f.files}          # shipped encoder (C = 30)
-    codebook = weights["vq_layer.embedding.weight"] if K == 512 else synth_codebook(K, D)
-    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=251)
+    if args.shape == "S":
+        with np.load(os.path.join(ROOT, "tests", "golden", "vq_vae_shipped.npz")) as f:
+            weights = {k: f[k] for k in f.files}          # shipped encoder (C = 30)
+    else:
+        from lbm_amd.synth import synth_encoder
+        weights = synth_encoder(C)
+    codebook = weights["vq_layer.embedding.weight"] if (K == 512 and args.shape == "S") else synth_codebook(K, D)
+    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -175,7 +189,8 @@ def main():
         for name, s_, e_ in pipe.stage_events:
             acc.setdefault(name, []).append(s_.elapsed_time(e_))
         pipe.stage_events = None
-        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F)
+        fft_n = 2048 if args.shape == "S" else 3 * 4096
+        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n)
         for name, ms in acc.items():
             m = float(np.mean(ms))
             stages[name] = {"ms": round(m, 4), "bound": model[name]["bound"],
@@ -186,10 +201,10 @@ def main():
         dom = max(stages, key=lambda k: stages[k]["ms"])      # the dominant single kernel of a chunk
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.shape == "S" and chunk == 16384 and K == 512:   # counters were taken on that launch
             with open(tpath) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
-        m = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F)[dom]
+        m = model[dom]
         if m["bound"] == "mfma":
             roof = {"kernel": KERNEL_OF_STAGE[dom], "bound": "mfma", "achieved": stages[dom]["tflops"], "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(stages[dom]["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic}
@@ -208,9 +223,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config3: full pipeline (825-tap FIR + ICA affine + baseline/reject/z-score + Welch PSD "
-                                   "+ band power + VQ-VAE encoder + K=%d codebook argmin), 30ch x 500Hz x 3s fp32 epochs, "
-                                   "%d epochs per step per GPU resident in HBM, walked in chunks of %d" % (K, E, chunk),
+            "config": {"workload": "%s: full pipeline (%d-tap FIR + ICA affine + baseline/reject/z-score + Welch PSD "
+                                   "+ band power + VQ-VAE encoder + K=%d codebook argmin), %dch x %gHz x %gs fp32 epochs, "
+                                   "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
+                                   % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
                        "codebook": K,
                        "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},

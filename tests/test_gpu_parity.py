@@ -388,6 +388,35 @@ def test_pipeline_matches_oracle(shipped, T):
     assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
 
 
+def test_pipeline_config_L_matches_oracle():
+    """BASELINE config 5 shape: 64 channels x 1 kHz x 10 s epochs, 1651-tap FIR, n_fft = 1000, 8192-entry codebook."""
+    from lbm_amd.synth import synth_encoder
+    C, T, fs, K = 64, 10000, 1000.0, 8192
+    taps = lbm_amd.create_filter(fs, 4.0, 30.0)
+    assert len(taps) == 1651
+    A, b = lbm_amd.ica_projection(**synth_ica(C))
+    weights = synth_encoder(C)
+    weights["vq_layer.embedding.weight"] = synth_codebook(K, 256) * 0.05
+    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=501)
+    pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, weights["vq_layer.embedding.weight"])
+    x = synth_epochs(2, C, T, sfreq=fs, seed=12)
+    out = pipe.run(x.to(DEV))
+    torch.cuda.synchronize()
+    want = orc.pipeline(x.numpy(), fs, taps, A, b, 501, 150e-6, weights)
+    assert _rms_ok(out["cleaned"].cpu().numpy(), want["filtered"]) <= 2e-5
+    assert np.array_equal(out["keep"].cpu().numpy().astype(bool), want["keep"])
+    assert out["psd"].shape == (2, C, 27)
+    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= 4.0
+    np.testing.assert_allclose(out["bandpower"].cpu().numpy(), want["bandpower"], rtol=2e-6)
+    tok = out["tokens"].cpu().numpy()
+    assert tok.shape == want["tokens"].shape == (2, 2500)
+    z = out["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+    cb = weights["vq_layer.embedding.weight"]
+    assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
+    assert (tok == want["tokens"]).mean() >= 0.95
+    assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=K))
+
+
 def test_pipeline_full_size_properties(shipped):
     """BASELINE-size chunk (4096 epochs of 30x1500): determinism, batch-split invariance, histogram checksum."""
     pipe, *_ = _make_pipeline(shipped)
