@@ -47,23 +47,6 @@ bool make_plan(int T, int ntaps, FftPlan* out) {
     return found;
 }
 
-// Sample m of the padded row in two halves, so that the global load can be issued one item ahead:
-// padded_index gives the (always valid) element to load, padded_value turns the loaded element into the
-// padded sample with selects only.  No load sits under a condition (a "load or zero" conditional would make
-// the compiler branch around each of the 32 loads and drain vmcnt).
-__device__ __forceinline__ int padded_index(int m, int T) {
-    const int idx = m < 0 ? -m : (m >= T ? 2 * (T - 1) - m : m);
-    return (idx >= 0 && idx < T) ? idx : 0;
-}
-__device__ __forceinline__ float padded_value(float v, int m, int T, bool reflect, float x0, float xl, bool live) {
-    const bool left = m < 0, right = m >= T;
-    const int idx = left ? -m : (right ? 2 * (T - 1) - m : m);
-    const bool ok = idx >= 0 && idx < T;
-    const float refl = 2.f * (left ? x0 : xl) - v;
-    const float out = (left || right) ? (reflect ? refl : 0.f) : v;
-    return (ok && live) ? out : 0.f;
-}
-
 // tables: float2 [N] Hq | [16][Q] stage-1 twiddles | [16][R3] stage-2 twiddles
 template <int R3>
 __global__ void fir_fft_tables_kernel(float2* __restrict__ tab, const float* __restrict__ taps, int ntaps) {
@@ -100,7 +83,7 @@ __global__ void fir_fft_tables_kernel(float2* __restrict__ tab, const float* __r
 template <int R3>
 __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
                                                           int ntaps, int pad_mode, int npairs, int Lb, long long items,
-                                                          const float2* __restrict__ tab) {
+                                                          const float2* __restrict__ tab, int vec) {
     constexpr int Q = 16 * R3, N = 16 * Q, NT = Q, G = 16 / R3;
     constexpr int A1S = Q + R3;          // stage-1 <-> stage-2 exchange: element (k1, j) at k1*A1S + j
     constexpr int A2S = 272 + 16 / R3;   // stage-2 <-> stage-3 exchange: element (k1, k2, n3) at n3*A2S + 17 k1 + k2
@@ -126,20 +109,30 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
     const int seg = Lb + ntaps - 1;      // input samples a block needs (<= N)
     const int k1 = t / R3, n3 = t % R3;  // stage-2 role of this thread
 
-    // raw samples of the NEXT item, loaded while the current one is transformed
-    float nre[16], nim[16], nx0, nxl;
+    // Input staging.  The item's window of the padded row -- padded indices [a0, a0 + Lb + N), i.e. samples
+    // ms = a0 - half onward -- is assembled in LDS (aliasing the exchange buffer): the real samples are copied
+    // in with 16-byte loads issued one item ahead (registers `pre`), the reflected / zero padding is derived
+    // from them in LDS, and then every thread picks its 2 x 16 transform inputs with plain ds_reads.  No
+    // per-sample address arithmetic or selects in the transform path; inputs past Lb + ntaps - 1 only reach
+    // discarded outputs, so they just have to be finite (they are written as 0).
+    constexpr int NPF = 8;               // quads per thread that cover a window: (Lb + N) / 4 / NT <= 8
+    float* const P = reinterpret_cast<float*>(s_x);
+    const int WL = Lb + N;               // LDS floats a transform pair reads
+    float4 pre[NPF];
+    auto window_start = [&](long long item) { return 2 * (int)(item % npairs) * Lb - half; };
     auto prefetch = [&](long long item) {
-        const long long row = item / npairs;
-        const int pair = (int)(item % npairs);
-        const float* xr = x + row * (long long)T;
-        const int a0 = 2 * pair * Lb, b0 = a0 + Lb;
-        nx0 = xr[0];
-        nxl = xr[T - 1];
+        const float* xr = x + (item / npairs) * (long long)T;
+        const int ms = window_start(item);
+        const int q0 = ms < 0 ? 0 : (ms & ~3);              // first sample of quad 0 (16-byte aligned when vec)
 #pragma unroll
-        for (int n1 = 0; n1 < 16; ++n1) {
-            const int p = t + Q * n1;
-            nre[n1] = xr[padded_index(a0 - half + p, T)];
-            nim[n1] = xr[padded_index(b0 - half + p, T)];
+        for (int i = 0; i < NPF; ++i) {
+            const int m = q0 + 4 * (t + NT * i);
+            if (vec) {
+                pre[i] = *reinterpret_cast<const float4*>(xr + (m + 3 < T ? m : 0));
+            } else {
+                pre[i] = make_float4(xr[m < T ? m : 0], xr[m + 1 < T ? m + 1 : 0], xr[m + 2 < T ? m + 2 : 0],
+                                     xr[m + 3 < T ? m + 3 : 0]);
+            }
         }
     };
     if ((long long)blockIdx.x < items) prefetch(blockIdx.x);
@@ -148,22 +141,54 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
         const long long row = item / npairs;
         const int pair = (int)(item % npairs);
         const int a0 = 2 * pair * Lb, b0 = a0 + Lb;
-        const bool has_a = a0 < T, has_b = b0 < T;
+        const bool has_b = b0 < T;
+        const int ms = a0 - half;
+        const int q0 = ms < 0 ? 0 : (ms & ~3);
 
-        float re[16], im[16];
-        {
-            float x0 = nx0, xl = nxl;
-            asm volatile("" : "+v"(x0), "+v"(xl));
+        // ---- real samples -> LDS (sample m sits at P[m - ms]); vec: T % 4 == 0, so a quad never straddles the row end
+        __syncthreads();   // the previous item's last exchange reads are done
+        const bool st4 = vec && !(ms & 3);
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int p = t + Q * n1;
-                const bool in = p < seg;
-                float vr = nre[n1], vi = nim[n1];
-                asm volatile("" : "+v"(vr), "+v"(vi));   // pins the loads: none may sink under a select
-                re[n1] = padded_value(vr, a0 - half + p, T, reflect, x0, xl, in && has_a);
-                im[n1] = padded_value(vi, b0 - half + p, T, reflect, x0, xl, in && has_b);
+        for (int i = 0; i < NPF; ++i) {
+            float4 v = pre[i];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // pins the loads (see conv.hip)
+            const int m = q0 + 4 * (t + NT * i);
+            const int l = m - ms;
+            if (st4 && l + 3 < WL) {
+                if (m < T) *reinterpret_cast<float4*>(P + l) = v;
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (m + c < T && l + c >= 0 && l + c < WL) P[l + c] = e[c];
             }
         }
+        __syncthreads();
+        // ---- padding, derived from the staged samples: left of sample 0, right of sample T-1
+        {
+            const int nl = ms < 0 ? (-ms < WL ? -ms : WL) : 0;
+            const float x0 = nl ? P[-ms] : 0.f;
+            for (int l = t; l < nl; l += NT) {
+                const int mm = -(ms + l);                    // reflect about sample 0
+                P[l] = (reflect && mm <= T - 1 && mm - ms < WL) ? 2.f * x0 - P[mm - ms] : 0.f;
+            }
+            const int r0 = T - ms;                           // first LDS slot right of the row (>= 1)
+            const float xl = r0 < WL ? P[r0 - 1] : 0.f;
+            for (int l = r0 + t; l < WL; l += NT) {
+                const int mm = 2 * (T - 1) - (ms + l);       // reflect about sample T-1
+                const bool live = l < Lb + seg;
+                P[l] = (reflect && live && mm >= 0 && mm >= ms) ? 2.f * xl - P[mm - ms] : 0.f;
+            }
+        }
+        __syncthreads();
+        float re[16], im[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int p = t + Q * n1;
+            re[n1] = P[p];
+            im[n1] = has_b ? P[Lb + p] : 0.f;
+        }
+        __syncthreads();   // the window is consumed; s_x becomes the exchange buffer
         {   // next item's loads fly under this item's transforms (the last item re-reads itself, unused)
             const long long nxt = item + gridDim.x;
             prefetch(nxt < items ? nxt : item);
@@ -299,8 +324,9 @@ int launch_fir(const float* x, float* y, int64_t rows, int T, int ntaps, int pad
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_fir_fft_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
+    const int vec = (T % 4 == 0) && (((uintptr_t)x & 15) == 0);   // every row starts 16-byte aligned
     hipLaunchKernelGGL(fir_fft_kernel<R3>, dim3((unsigned)grid), dim3(16 * R3), lds, s, x, y, T, ntaps, pad_mode, p.npairs,
-                       p.Lb, items, tab);
+                       p.Lb, items, tab, vec);
     return lbm::check_launch("lbm_fir_fft_f32");
 }
 
