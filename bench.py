@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 control flow on a box "
+                         "with fewer GPUs than ranks (ranks share devices, collectives staged through host memory)")
     ap.add_argument("--shape", choices=["S", "L"], default="S",
                     help="S = 30ch x 500Hz x 3s, K=512 (configs 3/4, the metric's workload); L = 64ch x 1kHz x 10s, "
                          "K=8192, 16384 epochs (config 5, for measurement only)")
@@ -103,13 +106,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     C, T, fs, K, D = (30, 1500, 500.0, args.codebook, 256) if args.shape == "S" else (64, 10000, 1000.0, args.codebook, 256)
     E, chunk = args.epochs, min(args.chunk, args.epochs)
@@ -152,9 +160,16 @@ def main():
             bp[lo:lo + n].copy_(out["bandpower"])
             keep[lo:lo + n].copy_(out["keep"])
         hist = pipe._buf["hist"]
-        if gathered is not None:
+        if gathered is not None and args.backend == "nccl":
             dist.all_gather_into_tensor(gathered.view(torch.uint8), tokens.view(torch.uint8))   # RCCL has no int16: bytes
             dist.all_reduce(hist)
+        elif gathered is not None:                      # gloo rehearsal: same calls on host copies
+            g_host = torch.empty(gathered.shape, dtype=gathered.dtype).view(torch.uint8)
+            dist.all_gather_into_tensor(g_host, tokens.cpu().view(torch.uint8))
+            gathered.view(torch.uint8).copy_(g_host)
+            h_host = hist.cpu()
+            dist.all_reduce(h_host)
+            hist.copy_(h_host)
         return hist
 
     for _ in range(args.warmup):
@@ -172,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
