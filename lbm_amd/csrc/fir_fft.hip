@@ -80,8 +80,11 @@ __global__ void fir_fft_tables_kernel(float2* __restrict__ tab, const float* __r
     }
 }
 
-template <int R3>
-__global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
+// NSUB independent items per workgroup (NSUB * N/16 threads): the sub-groups share the stage-1 twiddle table
+// and the barriers, which raises the waves per CU that fit next to the LDS (12 instead of 8 at N = 2048).
+// NPF: 16-byte quads per thread that cover one window's real samples (min(T, Lb + N) / 4 / (N/16), <= 8).
+template <int R3, int NPF, int NSUB>
+__global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
                                                           int ntaps, int pad_mode, int npairs, int Lb, long long items,
                                                           const float2* __restrict__ tab, int vec) {
     constexpr int Q = 16 * R3, N = 16 * Q, NT = Q, G = 16 / R3;
@@ -90,11 +93,12 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
     extern __shared__ __align__(16) float2 fft_smem[];
     float2* s_t1 = fft_smem;             // [k1][j]  w_N^{j k1}
     float2* s_t2 = s_t1 + N;             // [k2][n3] w_Q^{n3 k2}
-    float2* s_x = s_t2 + Q;              // [max(16*A1S, R3*A2S)]
+    constexpr int XCH = (16 * A1S > R3 * A2S) ? 16 * A1S : R3 * A2S;
+    const int t = threadIdx.x % NT, sub = threadIdx.x / NT;
+    float2* s_x = s_t2 + Q + sub * XCH;  // [XCH] per sub-group
 
-    const int t = threadIdx.x;
-    for (int i = t; i < N; i += NT) s_t1[i] = tab[N + i];
-    for (int i = t; i < Q; i += NT) s_t2[i] = tab[2 * N + i];
+    for (int i = threadIdx.x; i < N; i += NT * NSUB) s_t1[i] = tab[N + i];
+    for (int i = threadIdx.x; i < Q; i += NT * NSUB) s_t2[i] = tab[2 * N + i];
     float hre[16], him[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -115,7 +119,6 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
     // from them in LDS, and then every thread picks its 2 x 16 transform inputs with plain ds_reads.  No
     // per-sample address arithmetic or selects in the transform path; inputs past Lb + ntaps - 1 only reach
     // discarded outputs, so they just have to be finite (they are written as 0).
-    constexpr int NPF = 8;               // quads per thread that cover a window: (Lb + N) / 4 / NT <= 8
     float* const P = reinterpret_cast<float*>(s_x);
     const int WL = Lb + N;               // LDS floats a transform pair reads
     float4 pre[NPF];
@@ -135,9 +138,13 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
             }
         }
     };
-    if ((long long)blockIdx.x < items) prefetch(blockIdx.x);
+    // every sub-group runs every iteration (shared barriers); one past the end re-does the last item, stores off
+    const long long first = (long long)blockIdx.x * NSUB + sub;
+    prefetch(first < items ? first : items - 1);
 
-    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    for (long long base = (long long)blockIdx.x * NSUB; base < items; base += (long long)gridDim.x * NSUB) {
+        const bool active = base + sub < items;
+        const long long item = active ? base + sub : items - 1;
         const long long row = item / npairs;
         const int pair = (int)(item % npairs);
         const int a0 = 2 * pair * Lb, b0 = a0 + Lb;
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
         }
         __syncthreads();   // the window is consumed; s_x becomes the exchange buffer
         {   // next item's loads fly under this item's transforms (the last item re-reads itself, unused)
-            const long long nxt = item + gridDim.x;
-            prefetch(nxt < items ? nxt : item);
+            const long long nxt = base + (long long)gridDim.x * NSUB + sub;
+            prefetch(nxt < items ? nxt : items - 1);
         }
 
         // ---- forward stage 1
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(16 * R3) void fir_fft_kernel(const float* __restric
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) {
             const int o = t + Q * n1 - (ntaps - 1);
-            if (o >= 0 && o < Lb) {
+            if (active && o >= 0 && o < Lb) {
                 if (a0 + o < T) yr[a0 + o] = re[n1];
                 if (b0 + o < T) yr[b0 + o] = im[n1];
             }
@@ -309,25 +316,36 @@ int launch_tables(float2* tab, const float* taps, int ntaps, hipStream_t s) {
     return lbm::check_launch("lbm_fir_fft_tables_init");
 }
 
-template <int R3>
-int launch_fir(const float* x, float* y, int64_t rows, int T, int ntaps, int pad_mode, const FftPlan& p,
-               const float2* tab, hipStream_t s) {
+template <int R3, int NPF, int NSUB>
+int launch_fir_k(const float* x, float* y, int64_t rows, int T, int ntaps, int pad_mode, const FftPlan& p, const float2* tab,
+                 hipStream_t s) {
     const long long items = (long long)rows * p.npairs;
-    const int per_cu = (R3 == 4) ? 8 : (R3 == 8) ? 4 : 2;
-    long long grid = 256LL * per_cu;
-    if (grid > items) grid = items;
     constexpr int Q = 16 * R3, N = 16 * Q;
     constexpr int xch = (16 * (Q + R3) > R3 * (272 + 16 / R3)) ? 16 * (Q + R3) : R3 * (272 + 16 / R3);
-    constexpr size_t lds = (size_t)(N + Q + xch) * sizeof(float2);
+    constexpr size_t lds = (size_t)(N + Q + NSUB * xch) * sizeof(float2);
+    const int per_cu = (int)((160 * 1024) / lds) < 8 ? (int)((160 * 1024) / lds) : 8;
+    long long grid = 256LL * per_cu;
+    const long long need = (items + NSUB - 1) / NSUB;
+    if (grid > need) grid = need;
+    auto k = fir_fft_kernel<R3, NPF, NSUB>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_fft_kernel<R3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_fir_fft_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
     const int vec = (T % 4 == 0) && (((uintptr_t)x & 15) == 0);   // every row starts 16-byte aligned
-    hipLaunchKernelGGL(fir_fft_kernel<R3>, dim3((unsigned)grid), dim3(16 * R3), lds, s, x, y, T, ntaps, pad_mode, p.npairs,
-                       p.Lb, items, tab, vec);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(16 * R3 * NSUB), lds, s, x, y, T, ntaps, pad_mode, p.npairs, p.Lb, items, tab,
+                       vec);
     return lbm::check_launch("lbm_fir_fft_f32");
+}
+
+template <int R3, int NSUB>
+int launch_fir(const float* x, float* y, int64_t rows, int T, int ntaps, int pad_mode, const FftPlan& p, const float2* tab,
+               hipStream_t s) {
+    // quads per thread that cover the real samples of one window (+1 quad of alignment slack)
+    const int real = T < p.Lb + p.N ? T : p.Lb + p.N;
+    const int quads = (real + 3) / 4 + 1;
+    if (quads <= 4 * 16 * R3) return launch_fir_k<R3, 4, NSUB>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
+    return launch_fir_k<R3, 8, NSUB>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
 }
 
 }  // namespace
@@ -369,7 +387,7 @@ extern "C" int lbm_fir_fft_f32(const float* x, float* y, int64_t rows, int32_t T
     LBM_REQUIRE((long long)rows * p.npairs <= 0x7fffffffffffLL, LBM_EUNSUPPORTED, "lbm_fir_fft_f32: too many rows");
     const float2* tab = static_cast<const float2*>(tables);
     hipStream_t s = lbm::as_stream(stream);
-    if (p.R3 == 4) return launch_fir<4>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
-    if (p.R3 == 8) return launch_fir<8>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
-    return launch_fir<16>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
+    if (p.R3 == 4) return launch_fir<4, 2>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
+    if (p.R3 == 8) return launch_fir<8, 2>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
+    return launch_fir<16, 1>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
 }
