@@ -177,6 +177,25 @@ int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, co
 int lbm_vq_gather_loss_f32(const float* x, const float* codebook, const int64_t* idx, float* quantized,
                            double* sq_err_sum, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
 
+/* ---- EMA codebook training step -------------------------------------------------------
+ * Replaces the one-hot matmuls of VectorQuantizerEMA.forward in training mode, training/model.py:103-126.
+ * lbm_vq_ema_sums_f32: counts[k] = number of rows with idx == k (= sum(encodings, 0), :109-110) and
+ *   dw[k, :] = sum of those rows of x (= encodings^T @ flat_input, :122), as a deterministic segmented sum
+ *   (stable counting sort + fixed-order piecewise reduction; no float atomics, bitwise reproducible).
+ *   x: [N, D] rows with stride ldx; idx: [N] int64 (entries outside [0, K) are ignored); dw: [K, D];
+ *   counts: [K] uint64.  workspace: lbm_vq_ema_workspace_bytes(N, D, K) bytes of 16-byte aligned device
+ *   memory (0 = unsupported sizes: K > 8192).  D <= 1024, N < 2^32.  (counts, dw) are what data-parallel
+ *   ranks all-reduce before the apply step.
+ * lbm_vq_ema_apply_f32 (in place, fp32, the reference's operation order): cluster_size = cluster_size*decay +
+ *   (1-decay)*counts; n = sum(cluster_size); cluster_size = (cluster_size + eps)/(n + K*eps)*n;
+ *   ema_w = ema_w*decay + (1-decay)*dw; weight = ema_w / cluster_size[:, None]. */
+size_t lbm_vq_ema_workspace_bytes(int64_t N, int32_t D, int32_t K);
+int lbm_vq_ema_sums_f32(const float* x, int64_t ldx, const int64_t* idx, float* dw, unsigned long long* counts,
+                        void* workspace, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
+int lbm_vq_ema_apply_f32(float* ema_cluster_size, float* ema_w, float* weight, const float* dw,
+                         const unsigned long long* counts, int32_t K, int32_t D, float decay, float one_minus_decay,
+                         float eps, lbm_stream_t stream);
+
 /* training/model.py:142-144: perplexity = exp(-sum(p * log(p + 1e-10))), p = hist / sum(hist). out: [1]. */
 int lbm_perplexity_u64(const unsigned long long* hist, float* out, int32_t K, lbm_stream_t stream);
 

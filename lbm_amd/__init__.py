@@ -12,5 +12,5 @@ from .ica import ica_apply, ica_get_sources, ica_projection, affine_channels, av
 from .epochs import epoch_post, standardize_epochs, Scaler, n_baseline_samples  # noqa: F401
 from .psd import psd_array_welch, band_powers, classify_eeg_state, classify_eeg_state_variant  # noqa: F401
 from .quantizer import (VectorQuantizerEMA, VQVAE, encode_data_for_transformer, vq_argmin, conv1d,  # noqa: F401
-                        encoder_forward, rownorm2, vq_gather_loss, perplexity_from_hist)
+                        encoder_forward, rownorm2, vq_gather_loss, perplexity_from_hist, vq_ema_sums, vq_ema_apply)
 from .pipeline import EpochPipeline, PipelineConfig, shard_range, gather_epoch_outputs, allreduce_hist  # noqa: F401

@@ -74,6 +74,37 @@ def vq_gather_loss(x: torch.Tensor, codebook: torch.Tensor, idx: torch.Tensor, w
     return q, err
 
 
+def vq_ema_sums(flat_input: torch.Tensor, idx: torch.Tensor, K: int):
+    """(dw [K, D] fp32, counts [K] int64): the segmented sums of training/model.py:109-110,122 (deterministic)."""
+    x = _lib.dev_f32(flat_input)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    N, D = x.shape
+    lib = _lib.load()
+    nbytes = int(lib.lbm_vq_ema_workspace_bytes(N, D, K))
+    if nbytes == 0:
+        raise NotImplementedError(f"EMA sums support K <= 8192 (got K={K})")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    dw = torch.empty((K, D), dtype=torch.float32, device=x.device)
+    counts = torch.empty((K,), dtype=torch.int64, device=x.device)
+    idx = idx.reshape(-1).to(torch.int64).contiguous()
+    _lib.check(lib.lbm_vq_ema_sums_f32(_lib.ptr(x), x.stride(0) if N > 1 else D, _lib.ptr(idx), _lib.ptr(dw), _lib.ptr(counts),
+                                       _lib.ptr(ws), N, D, K, _lib.stream_ptr()), "lbm_vq_ema_sums_f32")
+    return dw, counts
+
+
+def vq_ema_apply(ema_cluster_size: torch.Tensor, ema_w: torch.Tensor, weight: torch.Tensor, dw: torch.Tensor,
+                 counts: torch.Tensor, decay: float, epsilon: float):
+    """In-place EMA codebook update (training/model.py:109-126) on fp32 CUDA tensors."""
+    for t in (ema_cluster_size, ema_w, weight, dw):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("EMA state must be contiguous float32 CUDA tensors")
+    K, D = ema_w.shape
+    _lib.check(_lib.load().lbm_vq_ema_apply_f32(_lib.ptr(ema_cluster_size), _lib.ptr(ema_w), _lib.ptr(weight), _lib.ptr(dw),
+                                                _lib.ptr(counts.contiguous()), K, D, float(decay), float(1 - decay),
+                                                float(epsilon), _lib.stream_ptr()), "lbm_vq_ema_apply_f32")
+
+
 def perplexity_from_hist(hist: torch.Tensor) -> torch.Tensor:
     """exp(-sum p log(p + 1e-10)), p = hist / sum(hist)  (training/model.py:142-144)."""
     out = torch.empty((1,), dtype=torch.float32, device=hist.device)
@@ -179,15 +210,18 @@ class VectorQuantizerEMA(nn.Module):
             # differentiable gather with the PRE-update codebook (training/model.py:100)
             quantized = F.embedding(idx, w).view(input_shape)
         if self.training:
-            # EMA codebook update (training/model.py:103-126); segmented sums instead of one-hot matmuls
+            # EMA codebook update (training/model.py:103-126): deterministic segmented sums instead of the
+            # one-hot matmuls, then the in-place EMA kernel.  With `ema_group` set (one process per GPU), the
+            # (counts, dw) pair is all-reduced first, so every rank applies the same global update.
             with torch.no_grad():
-                counts = hist.to(torch.float32)
-                self.ema_cluster_size = self.ema_cluster_size * self.decay + (1 - self.decay) * counts
-                n = torch.sum(self.ema_cluster_size)
-                self.ema_cluster_size = ((self.ema_cluster_size + self.epsilon) / (n + K * self.epsilon) * n)
-                dw = torch.zeros_like(self.ema_w).index_add_(0, idx, flat_input.detach())
-                self.ema_w = self.ema_w * self.decay + (1 - self.decay) * dw
-                self.embedding.weight.data.copy_(self.ema_w / self.ema_cluster_size.unsqueeze(1))
+                dw, counts = vq_ema_sums(flat_input.detach(), idx, K)
+                group = getattr(self, "ema_group", None)
+                if group is not None:
+                    import torch.distributed as dist
+                    dist.all_reduce(counts, group=group)
+                    dist.all_reduce(dw, group=group)
+                vq_ema_apply(self.ema_cluster_size, self.ema_w, self.embedding.weight.data, dw, counts, self.decay,
+                             self.epsilon)
         if self.training or grad_path:
             e_latent_loss = F.mse_loss(quantized.detach(), inputs)
             q_latent_loss = F.mse_loss(quantized, inputs.detach())

@@ -344,6 +344,51 @@ def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
     assert gi.shape == (1024,) and gi.dtype == torch.int64
 
 
+def test_vq_ema_training_step_golden(shipped, vq_golden):
+    """VectorQuantizerEMA.forward in training mode: EMA buffers and codebook after one step (training/model.py:103-126)."""
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
+    vq = m.vq_layer.to(DEV).train()
+    x = torch.from_numpy(vq_golden["ema_in"]).to(DEV)
+    loss, quant, perp, idx = vq(x)
+    same = (idx.cpu().numpy() == vq_golden["ema_idx"])
+    assert same.mean() >= 0.97
+    if same.all():
+        np.testing.assert_allclose(vq.ema_cluster_size.cpu().numpy(), vq_golden["ema_cluster_size"], rtol=1e-6)
+        np.testing.assert_allclose(vq.ema_w.cpu().numpy(), vq_golden["ema_w"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(vq.embedding.weight.detach().cpu().numpy(), vq_golden["ema_weight"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(float(loss.detach()), vq_golden["ema_loss"], rtol=1e-5)
+    # the kernels against the oracle with the reference's own indices (independent of argmin near-ties)
+    flat = vq_golden["ema_in"].reshape(-1, 256)
+    ridx = vq_golden["ema_idx"].reshape(-1)
+    dw, counts = lbm_amd.vq_ema_sums(torch.from_numpy(flat).to(DEV), torch.from_numpy(ridx).to(DEV), 512)
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(ridx, minlength=512))
+    cs = torch.from_numpy(shipped["vq_layer.ema_cluster_size"]).to(DEV).clone()
+    ew = torch.from_numpy(shipped["vq_layer.ema_w"]).to(DEV).clone()
+    w = torch.empty_like(ew)
+    lbm_amd.vq_ema_apply(cs, ew, w, dw, counts, 0.99, 1e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), vq_golden["ema_cluster_size"], rtol=1e-6)
+    np.testing.assert_allclose(ew.cpu().numpy(), vq_golden["ema_w"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(w.cpu().numpy(), vq_golden["ema_weight"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,D,K", [(200000, 256, 512), (50000, 64, 8192), (777, 72, 5), (0, 256, 512), (3, 256, 512)])
+def test_vq_ema_sums_match_numpy_and_are_deterministic(N, D, K):
+    rs = np.random.RandomState(N % 1000 + K)
+    x = rs.randn(N, D).astype(np.float32)
+    # skewed code usage: a few popular codes (long runs -> several reduction pieces), many empty ones
+    idx = np.minimum((rs.exponential(0.08, N) * K).astype(np.int64), K - 1)
+    xd, idd = torch.from_numpy(x).to(DEV), torch.from_numpy(idx).to(DEV)
+    dw, counts = lbm_amd.vq_ema_sums(xd, idd, K)
+    dw2, counts2 = lbm_amd.vq_ema_sums(xd, idd, K)
+    assert torch.equal(dw, dw2) and torch.equal(counts, counts2)          # bitwise reproducible
+    assert np.array_equal(counts.cpu().numpy(), np.bincount(idx, minlength=K))
+    want = np.zeros((K, D))
+    np.add.at(want, idx, x.astype(np.float64))
+    scale = np.sqrt(np.maximum(np.bincount(idx, minlength=K), 1))[:, None]
+    assert float((np.abs(dw.cpu().numpy() - want) / scale).max()) <= 2e-5
+
+
 def test_encode_data_for_transformer_signature(shipped):
     m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
