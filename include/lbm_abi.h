@@ -73,6 +73,14 @@ int lbm_fir_fft_f32(const float* x, float* y, int64_t rows, int32_t T, const voi
 int lbm_affine_ch_f32(const float* x, float* y, int64_t E, int32_t Cin, int32_t Cout, int32_t T,
                       const float* A, const float* b, lbm_stream_t stream);
 
+/* ---- a4 (slicing): epochs from a continuous recording ------------------------------------------------
+ * Replaces the window extraction of mne.Epochs(raw, events, tmin, tmax) at training/preprocess.py:262-271,
+ * multi-train/withpsd.py:213-216: out[e, c, t] = raw[c, starts[e] + t], t < Tw.  raw: [C, Trec] with row
+ * pitch ldr; starts: [E] int64 device array (event sample + round(tmin*sfreq)); out: [E, C, Tw].
+ * Samples outside [0, Trec) read as 0 (MNE drops such events; lbm_amd.make_epochs does too). */
+int lbm_epochs_gather_f32(const float* raw, int64_t ldr, const int64_t* starts, float* out, int64_t E, int32_t C,
+                          int32_t Tw, int64_t Trec, lbm_stream_t stream);
+
 /* ---- a4 / a5 / a6: epoch post-processing ----------------------------------------------------------
  * Replaces mne.Epochs(..., baseline=(None, 0)) baseline correction (training/preprocess.py:262-271),
  * reject=dict(eeg=150e-6)+drop_bad (multi-train/withpsd.py:44-46,213-219) and the per-epoch

@@ -9,7 +9,8 @@ from .constants import *  # noqa: F401,F403
 from . import _lib  # noqa: F401
 from .filter import create_filter, filter_data, notch_filter, fir_apply  # noqa: F401
 from .ica import ica_apply, ica_get_sources, ica_projection, affine_channels, average_reference_matrix  # noqa: F401
-from .epochs import epoch_post, standardize_epochs, Scaler, n_baseline_samples  # noqa: F401
+from .epochs import (epoch_post, standardize_epochs, Scaler, n_baseline_samples, make_epochs,  # noqa: F401
+                     save_preprocess_outputs, save_withpsd_outputs)
 from .psd import psd_array_welch, band_powers, classify_eeg_state, classify_eeg_state_variant  # noqa: F401
 from .quantizer import (VectorQuantizerEMA, VQVAE, encode_data_for_transformer, vq_argmin, conv1d,  # noqa: F401
                         encoder_forward, rownorm2, vq_gather_loss, perplexity_from_hist, vq_ema_sums, vq_ema_apply)

@@ -20,6 +20,56 @@ def n_baseline_samples(tmin: float, sfreq: float, b_end: float = 0.0) -> int:
     return int(round((b_end - tmin) * sfreq)) + 1
 
 
+def make_epochs(raw: torch.Tensor, event_samples, tmin: float, tmax: float, sfreq: float, first_samp: int = 0):
+    """Window extraction of ``mne.Epochs(raw, events, tmin=tmin, tmax=tmax)`` (training/preprocess.py:262-271).
+
+    raw: [C, T_rec] (CUDA or array-like); event_samples: event sample indices (column 0 of the MNE events
+    array).  Returns (x[E_kept, C, Tw] float32 CUDA, kept: bool numpy mask over the events); an event whose
+    window [s + round(tmin*sfreq), s + round(tmax*sfreq)] leaves the recording is dropped, as MNE does.
+    Baseline correction / rejection / z-score are ``epoch_post`` on the result."""
+    import numpy as np
+    raw = _lib.dev_f32(raw)
+    if raw.dim() != 2:
+        raise ValueError("raw must be [channels, samples]")
+    if raw.stride(1) != 1:
+        raw = raw.contiguous()
+    Cc, Trec = raw.shape
+    ev = np.asarray(event_samples, dtype=np.int64).reshape(-1) - int(first_samp)
+    lo, hi = int(round(tmin * sfreq)), int(round(tmax * sfreq))
+    Tw = hi - lo + 1
+    kept = (ev + lo >= 0) & (ev + hi < Trec)
+    starts = torch.from_numpy(ev[kept] + lo).to(raw.device)
+    E = int(kept.sum())
+    out = torch.empty((E, Cc, Tw), dtype=torch.float32, device=raw.device)
+    _lib.check(_lib.load().lbm_epochs_gather_f32(_lib.ptr(raw), raw.stride(0) if Cc > 1 else Trec, _lib.ptr(starts), _lib.ptr(out),
+                                                 E, Cc, Tw, Trec, _lib.stream_ptr()), "lbm_epochs_gather_f32")
+    return out, kept
+
+
+def save_preprocess_outputs(prefix: str, standardized_epochs, labels) -> Tuple[str, str]:
+    """training/preprocess.py:35-36,303-304: ``<prefix>_epochs_ica_std.npy`` (float64, as MNE/NumPy produce)
+    and ``<prefix>_labels.npy``."""
+    import numpy as np
+    a, b = f"{prefix}_epochs_ica_std.npy", f"{prefix}_labels.npy"
+    x = standardized_epochs.detach().cpu().numpy() if isinstance(standardized_epochs, torch.Tensor) else np.asarray(standardized_epochs)
+    np.save(a, x.astype(np.float64))
+    np.save(b, np.asarray(labels))
+    return a, b
+
+
+def save_withpsd_outputs(prefix: str, time_epochs, psd_epochs, psd_freqs, labels):
+    """multi-train/withpsd.py:61-66,394-414: ``*_time_epochs.npy``, ``*_psd_epochs.npy``, ``*_psd_freqs.npy``,
+    ``*_labels.npy`` (float64 arrays on disk like the reference's)."""
+    import numpy as np
+    host = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)  # noqa: E731
+    paths = [f"{prefix}_time_epochs.npy", f"{prefix}_psd_epochs.npy", f"{prefix}_psd_freqs.npy", f"{prefix}_labels.npy"]
+    np.save(paths[0], host(time_epochs).astype(np.float64))
+    np.save(paths[1], host(psd_epochs).astype(np.float64))
+    np.save(paths[2], host(psd_freqs).astype(np.float64))
+    np.save(paths[3], host(labels))
+    return paths
+
+
 def epoch_post(x: torch.Tensor, *, n_baseline: int = 0, reject: Optional[float] = None, standardize: bool = False,
                eps: float = ZSCORE_EPSILON, inplace_baseline: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:

@@ -106,6 +106,32 @@ def test_fir_linearity_at_full_size():
         assert _rms_ok(y1[e, c].cpu().numpy(), want) <= 1e-5
 
 
+def test_continuous_recording_order_filter_ica_then_epochs(tmp_path):
+    """The reference's exact order (training/preprocess.py:77 -> 144 -> 262-287): filter and clean the CONTINUOUS
+    recording, then cut epochs, baseline-correct, z-score, save with the reference's file names."""
+    C, Trec, fs = 6, 60000, 500.0
+    raw = synth_epochs(1, C, Trec, sfreq=fs, seed=31)[0]
+    taps = lbm_amd.create_filter(fs, 4.0, 30.0)
+    kw = synth_ica(C, exclude=(1,))
+    events = np.array([100, 700, 5000, 5001, 30000, 59200, 59900])       # first and last windows leave the recording
+    rawd = raw.to(DEV)
+    filt = lbm_amd.fir_apply(rawd, taps)                                  # long rows: many block pairs per row
+    want_f = orc.fir_zero_phase(raw.numpy().astype(np.float64), taps)
+    assert _rms_ok(filt.cpu().numpy(), want_f) <= 1e-5
+    clean = lbm_amd.ica_apply(filt[None], **kw)[0]
+    x, kept = lbm_amd.make_epochs(clean, events, lbm_amd.TMIN, lbm_amd.TMAX, fs)
+    assert kept.tolist() == [False, True, True, True, True, True, False] and x.shape == (5, C, 1001)
+    want_c = orc.ica_apply(want_f[None], **kw)[0]
+    want_x = np.stack([want_c[:, s - 250:s + 751] for s in events[kept]])
+    assert _rms_ok(x.cpu().numpy(), want_x) <= 2e-5
+    base, std, _ = lbm_amd.epoch_post(x, n_baseline=lbm_amd.n_baseline_samples(lbm_amd.TMIN, fs), standardize=True)
+    wb = orc.baseline_correct(want_x, 251)
+    assert float(np.abs(std.cpu().numpy() - orc.zscore_epoch_channel(wb)).max()) <= 1e-4
+    a, b = lbm_amd.save_preprocess_outputs(str(tmp_path / "s02_051115m"), std, np.array(["alert"] * 5))
+    assert a.endswith("s02_051115m_epochs_ica_std.npy") and np.load(a).dtype == np.float64 and np.load(a).shape == (5, C, 1001)
+    assert np.load(b).shape == (5,)
+
+
 # ------------------------------------------------------------------------------------------------ a3 ICA
 @pytest.mark.parametrize("C,T", [(30, 1500), (30, 1001), (64, 1000), (5, 7)])
 def test_ica_apply_matches_oracle(C, T):
