@@ -160,17 +160,50 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
     const float inv_n = 1.f / (float)g.N;
     const int ke0 = bin_lo + (bin_lo & 1), ko0 = bin_lo + 1 - (bin_lo & 1);
 
-    for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < ngroups; grp += (int64_t)gridDim.x * waves_per_block) {
+    // Row staging.  With one wavefront per SIMD nothing hides an HBM round trip, so the NEXT group's rows are
+    // loaded into registers (kPFQ quads per lane) while the current group is transformed, and only written to
+    // LDS at the top of the next iteration.  Groups too large for the registers (or unaligned rows) use
+    // batches of 8 loads in flight instead.
+    constexpr int kPFQ = 24;
+    const int64_t gstride = (int64_t)gridDim.x * waves_per_block;
+    const bool use_pf = ((T & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && (g.RW * T <= 4 * 64 * kPFQ);
+    float4 pre[kPFQ];
+    auto prefetch = [&](int64_t grp) {
+        const int64_t row0 = grp * g.RW;
+        const int nrows = (int)((rows - row0) < g.RW ? (rows - row0) : g.RW);
+        const int n4 = (nrows * T) >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(x + row0 * (int64_t)T);
+#pragma unroll
+        for (int u = 0; u < kPFQ; ++u) {
+            const int idx = u * 64 + lane;
+            pre[u] = src4[idx < n4 ? idx : n4 - 1];
+        }
+    };
+    const int64_t grp_first = (int64_t)blockIdx.x * waves_per_block + wave;
+    if (use_pf && grp_first < ngroups) prefetch(grp_first);
+
+    for (int64_t grp = grp_first; grp < ngroups; grp += gstride) {
         const int64_t row0 = grp * g.RW;
         const int nrows = (int)((rows - row0) < g.RW ? (rows - row0) : g.RW);
         const int nsegs = nrows * g.nseg;
         // ---- stage the group's rows (contiguous in x) into this wave's LDS
-        {
+        if (use_pf) {
+            const int n4 = (nrows * T) >> 2;
+#pragma unroll
+            for (int u = 0; u < kPFQ; ++u) {
+                float4 v = pre[u];
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+                const int idx = u * 64 + lane;
+                if (idx < n4) reinterpret_cast<float4*>(s_rows)[idx] = v;
+            }
+            const int64_t nxt = grp + gstride;
+            prefetch(nxt < ngroups ? nxt : grp);   // flies under this group's transforms (the last one re-reads itself)
+        } else {
             const float* src = x + row0 * (int64_t)T;
             const int nfl = nrows * T;
             if ((((uintptr_t)src) & 15) == 0) {
                 // batches of 8 loads in flight per lane: a rolled "load, wait, write" loop pays one HBM round
-                // trip per float4 (18 per group at 3 rows x 1500 samples)
+                // trip per float4
                 const int n4 = nfl >> 2;
                 const float4* src4 = reinterpret_cast<const float4*>(src);
                 for (int i0 = 0; i0 < n4; i0 += 64 * 8) {
@@ -193,13 +226,27 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- per-segment means
-        for (int sg = 0; sg < nsegs; ++sg) {
-            const float* base = s_rows + (sg / g.nseg) * T + (sg % g.nseg) * g.hop;
-            float sum = 0.f;
-            for (int n = lane; n < g.N; n += 64) sum += base[n];
-            sum = lbm::wave_sum(sum);
-            if (lane == 0) s_mean[sg] = sum * inv_n;
+        // ---- per-segment means: 4 lanes per segment, each sums every 4th group of 8 samples with 8 loads in
+        // flight (a wave-wide reduction per segment costs 6 dependent cross-lane steps; one lane per segment
+        // walking N samples pays an LDS round trip per step)
+        for (int sg0 = 0; sg0 < nsegs; sg0 += 16) {
+            const int sg = sg0 + (lane >> 2), part = lane & 3;
+            const int sgc = sg < nsegs ? sg : nsegs - 1;
+            const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int n = 8 * part;
+            for (; n + 8 <= g.N; n += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += base[n + u];
+            }
+            if (n < g.N) {   // ragged tail group of this lane
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += (n + u < g.N) ? base[n + u] : 0.f;
+            }
+            float sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            if (part == 0 && sg < nsegs) s_mean[sg] = sum * inv_n;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- folded pruned DFT, 16 segments per MFMA tile
@@ -209,34 +256,50 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
             const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
             const float m = s_mean[sgc];
             const float* bb = s_basis + j * g.LDB;
-            f32x4 re_e = {0.f, 0.f, 0.f, 0.f}, im_e = re_e, re_o = re_e, im_o = re_e;
-#pragma unroll 2
-            for (int t = 0; t < g.QS; ++t) {
+            f32x4 acc[4];   // re_e, im_e, re_o, im_o
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // operands of k-step t: the four folded samples, two window values, four basis values.  They are
+            // loaded one step ahead (explicit software pipeline: the compiler does not unroll this runtime-length
+            // loop, and with one wavefront per SIMD every LDS round trip would otherwise sit between the MFMAs)
+            struct Ops { float d1, d2, d3, d4, w1, w2; float4 bs; int nc; };
+            auto load_ops = [&](int t) {
+                Ops o;
                 const int n = 4 * t + kq;
-                const int nc = n < g.Q ? n : g.Q;
-                const float d1 = base[nc] - m;
-                const float d3 = base[g.H - nc] - m;
-                float d2 = base[g.N - (nc ? nc : 1)] - m;   // d[N-n]; d[N] does not exist -> 0
-                float d4 = base[g.H + nc] - m;              // d[H+n]; at n == 0 it is d[H] again -> 0
-                if (nc == 0) { d2 = 0.f; d4 = 0.f; }
-                const float w1 = s_win[nc], w2 = s_win[g.H - nc];
-                const float a1 = w1 * (d1 + d2), a2 = w2 * (d3 + d4);
-                const float b1 = w1 * (d1 - d2), b2 = w2 * (d3 - d4);
-                const float f = (nc == g.Q) ? 0.5f : 1.f;   // the middle term pairs with itself
+                o.nc = n < g.Q ? n : g.Q;
+                o.d1 = base[o.nc];
+                o.d3 = base[g.H - o.nc];
+                o.d2 = base[g.N - (o.nc ? o.nc : 1)];   // d[N-n]; d[N] does not exist -> 0 below
+                o.d4 = base[g.H + o.nc];                // d[H+n]; at n == 0 it is d[H] again -> 0 below
+                o.w1 = s_win[o.nc];
+                o.w2 = s_win[g.H - o.nc];
+                o.bs = *reinterpret_cast<const float4*>(bb + 4 * n);
+                return o;
+            };
+            Ops cur = load_ops(0);
+            for (int t = 0; t < g.QS; ++t) {
+                const Ops nxt = load_ops(t + 1 < g.QS ? t + 1 : t);
+                __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's VALU/MFMA
+                const float d1 = cur.d1 - m, d3 = cur.d3 - m;
+                float d2 = cur.d2 - m, d4 = cur.d4 - m;
+                if (cur.nc == 0) { d2 = 0.f; d4 = 0.f; }
+                const float a1 = cur.w1 * (d1 + d2), a2 = cur.w2 * (d3 + d4);
+                const float b1 = cur.w1 * (d1 - d2), b2 = cur.w2 * (d3 - d4);
+                const float f = (cur.nc == g.Q) ? 0.5f : 1.f;   // the middle term pairs with itself
                 const float ce = f * (a1 + a2), co = a1 - a2, se = b1 - b2, so = f * (b1 + b2);
-                const float4 bs = *reinterpret_cast<const float4*>(bb + 4 * n);
-                re_e = __builtin_amdgcn_mfma_f32_16x16x4f32(ce, bs.x, re_e, 0, 0, 0);
-                im_e = __builtin_amdgcn_mfma_f32_16x16x4f32(se, bs.y, im_e, 0, 0, 0);
-                re_o = __builtin_amdgcn_mfma_f32_16x16x4f32(co, bs.z, re_o, 0, 0, 0);
-                im_o = __builtin_amdgcn_mfma_f32_16x16x4f32(so, bs.w, im_o, 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ce, cur.bs.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(se, cur.bs.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(co, cur.bs.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(so, cur.bs.w, acc[3], 0, 0, 0);
+                cur = nxt;
             }
             // accumulator: column = bin slot j (lane & 15), rows = segments 4*kq + r
             const int ie = ke0 + 2 * j - bin_lo, io = ko0 + 2 * j - bin_lo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float* prow = s_P + (tile * 16 + 4 * kq + r) * kLdp;
-                if (ie < F) prow[ie] = fmaf(re_e[r], re_e[r], im_e[r] * im_e[r]);
-                if (io < F) prow[io] = fmaf(re_o[r], re_o[r], im_o[r] * im_o[r]);
+                if (ie < F) prow[ie] = fmaf(acc[0][r], acc[0][r], acc[1][r] * acc[1][r]);
+                if (io < F) prow[io] = fmaf(acc[2][r], acc[2][r], acc[3][r] * acc[3][r]);
             }
         }
         __builtin_amdgcn_wave_barrier();
