@@ -243,6 +243,204 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------- Winograd F(2,3) path
+// conv_wino3_kernel<VEC>: ksize 3, stride 1, pad 1 (the encoder's 128 -> 256 layer) with the minimal-filtering
+// identity F(2,3): for the output pair (2j, 2j+1) and d_k = x[2j-1+k],
+//   V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3;  U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
+//   M_i = sum_ci U_i[co,ci] * V_i[ci,j];   y[2j] = M0+M1+M2,  y[2j+1] = M1-M2-M3
+// i.e. four GEMMs with K = Cin over HALF the positions: 2/3 of the direct form's MFMA work.  Same tile and
+// pipeline as conv_tile_kernel (128 positions = 64 pairs x 128 channels, pairs as the MFMA M operand); the
+// V's are formed on the fly from four raw-window reads per input channel, the U's when the weight slab is
+// staged.  fp32 throughout; differs from the direct form by a few ulp of |x||w| (the same order as the
+// difference between two BLAS libraries; vendor conv libraries use this transform for 3-tap fp32 convs).
+struct WinoCfg {
+    static constexpr int BM = 128, CK = 8;
+    static constexpr int LDU = CK + 4;                   // padded U row (conflict-free ds_read_b128)
+    static constexpr int XW = ((BN - 1) + 3 + 4 + 3) & ~3;   // window samples per channel row (as ConvCfg<3,1>)
+    static constexpr int X4 = XW / 4;
+    static constexpr int X_F4 = (CK * X4 + kThreads - 1) / kThreads;
+    static constexpr int USZ = 4 * BM * LDU, XSZ = CK * XW;
+    static constexpr size_t LDS_FLOATS = 2 * (size_t)(USZ + XSZ);
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int Cin, int Lin, int ldx, int Cout, int Lout, int ldy,
+                                                              int relu, int ptiles, int mtiles) {
+    using Cfg = WinoCfg;
+    constexpr int BM = Cfg::BM, CK = Cfg::CK, LDU = Cfg::LDU, XW = Cfg::XW, X4 = Cfg::X4, CN = 2;
+    extern __shared__ __align__(16) float smem[];
+    float* const s_u0 = smem;                  // 2 x [4][BM][LDU]  transformed weights
+    float* const s_x0 = smem + 2 * Cfg::USZ;   // 2 x [CK][XW]      raw input windows
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mt = blockIdx.x % mtiles;
+    const int rest = blockIdx.x / mtiles;
+    const int pt = rest % ptiles;
+    const int64_t b = rest / ptiles;
+    const int m0 = mt * BM, p0 = pt * BN;
+    const int ga = p0 - 4;                     // first sample of the window (pad = 1, aligned start 4 early)
+    const float* xb = x + b * (int64_t)Cin * ldx;
+
+    float bv[CN];
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn) {
+        const int co = m0 + wm * 64 + cn * 32 + j;
+        bv[cn] = 0.f;
+        if (bias != nullptr && co < Cout) bv[cn] = bias[co];
+    }
+
+    // weights: thread -> (channel co = tid / 2, input-channel quad cq = tid & 1): 12 consecutive floats
+    // w[co][ci0 + 4 cq .. +3][0..2] = three 16-byte loads (Cin % 4 == 0 keeps them aligned)
+    const int u_co = threadIdx.x >> 1, u_cq = threadIdx.x & 1;
+    const bool u_ok = m0 + u_co < Cout;
+    const int u_off = ((u_ok ? m0 + u_co : 0) * Cin + 4 * u_cq) * 3;
+    float4 rw[3];
+    float4 rx[Cfg::X_F4];
+    int x_o[Cfg::X_F4][VEC == 4 ? 1 : 4], x_lds[Cfg::X_F4];
+    bool x_ok[Cfg::X_F4][4];
+#pragma unroll
+    for (int i = 0; i < Cfg::X_F4; ++i) {
+        const int f = threadIdx.x + i * kThreads;
+        const bool slot = f < CK * X4;
+        const int r = slot ? f / X4 : 0, c4 = slot ? f - r * X4 : 0;
+        const int g = ga + 4 * c4;
+        x_lds[i] = r * XW + 4 * c4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x_ok[i][e] = slot && (unsigned)(g + e) < (unsigned)Lin;
+        if constexpr (VEC == 4) {
+            x_o[i][0] = r * ldx + (g < 0 ? 0 : (g > ldx - 4 ? ldx - 4 : g));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x_o[i][e] = r * ldx + (g + e < 0 ? 0 : (g + e < Lin ? g + e : Lin - 1));
+        }
+    }
+
+    auto load_chunk = [&](int ch) {
+        const float* wc = w + ch * CK * 3;
+        const float* xc = xb + (int64_t)ch * CK * ldx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const float4*>(wc + u_off + 4 * i);
+#pragma unroll
+        for (int i = 0; i < Cfg::X_F4; ++i) {
+            if constexpr (VEC == 4) rx[i] = load_quad<4>(xc, x_o[i][0], 0, 0, 0);
+            else rx[i] = load_quad<1>(xc, x_o[i][0], x_o[i][1], x_o[i][2], x_o[i][3]);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float* su = s_u0 + buf * Cfg::USZ + u_co * LDU + 4 * u_cq;
+        float* sx = s_x0 + buf * Cfg::XSZ;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(rw[i].x), "+v"(rw[i].y), "+v"(rw[i].z), "+v"(rw[i].w));
+        const float g[12] = {rw[0].x, rw[0].y, rw[0].z, rw[0].w, rw[1].x, rw[1].y, rw[1].z, rw[1].w,
+                             rw[2].x, rw[2].y, rw[2].z, rw[2].w};   // [ci 0..3][tap 0..2]
+        float u[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float g0 = u_ok ? g[3 * c] : 0.f, g1 = u_ok ? g[3 * c + 1] : 0.f, g2 = u_ok ? g[3 * c + 2] : 0.f;
+            u[0][c] = g0;
+            u[1][c] = ((g0 + g2) + g1) * 0.5f;
+            u[2][c] = ((g0 + g2) - g1) * 0.5f;
+            u[3][c] = g2;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(su + i * (BM * LDU)) = make_float4(u[i][0], u[i][1], u[i][2], u[i][3]);
+#pragma unroll
+        for (int i = 0; i < Cfg::X_F4; ++i) {
+            asm volatile("" : "+v"(rx[i].x), "+v"(rx[i].y), "+v"(rx[i].z), "+v"(rx[i].w));
+            if (threadIdx.x + i * kThreads < CK * X4)
+                *reinterpret_cast<float4*>(sx + x_lds[i]) =
+                    make_float4(x_ok[i][0] ? rx[i].x : 0.f, x_ok[i][1] ? rx[i].y : 0.f, x_ok[i][2] ? rx[i].z : 0.f,
+                                x_ok[i][3] ? rx[i].w : 0.f);
+        }
+    };
+
+    f32x16 acc[4][CN];   // [transform i][channel sub-tile]; rows = output pairs
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][cn][r] = 0.f;
+
+    // input channels h*4 + s, s in [slo, shi), of LDS image `buf`.  Pair jl = wn*32 + j of the tile needs the
+    // samples 2 jl - 1 .. 2 jl + 2 relative to p0, i.e. window slots 2 jl + 3 .. 2 jl + 6.
+    const int xsh = 2 * (wn * 32 + j) + 3;
+    auto mfma_block = [&](int buf, int slo, int shi) {
+        const float* up = s_u0 + buf * Cfg::USZ + (wm * 64 + j) * LDU + h * 4;
+        const float* xp = s_x0 + buf * Cfg::XSZ + (h * 4) * XW + xsh;
+        float uv[4][CN][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int cn = 0; cn < CN; ++cn) {
+                const float4 t = *reinterpret_cast<const float4*>(up + i * (BM * LDU) + cn * 32 * LDU);
+                uv[i][cn][0] = t.x; uv[i][cn][1] = t.y; uv[i][cn][2] = t.z; uv[i][cn][3] = t.w;
+            }
+#pragma unroll
+        for (int s = slo; s < shi; ++s) {
+            const float d0 = xp[s * XW], d1 = xp[s * XW + 1], d2 = xp[s * XW + 2], d3 = xp[s * XW + 3];
+            const float v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn)
+                    acc[i][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i], uv[i][cn][s], acc[i][cn], 0, 0, 0);
+        }
+    };
+
+    const int nchunks = Cin / CK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    load_chunk(nchunks > 1 ? 1 : 0);
+    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+        const int buf = ch & 1;
+        mfma_block(buf, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);   // keep the wait for chunk ch+1's loads behind the first half's MFMAs
+        store_chunk(buf ^ 1);
+        load_chunk(ch + 2 < nchunks ? ch + 2 : nchunks - 1);
+        mfma_block(buf, 2, 4);
+        __syncthreads();
+    }
+    mfma_block((nchunks - 1) & 1, 0, 4);
+
+    // Epilogue: accumulator register quad rq of a lane = output pairs 8*rq + 4*h + (0..3) of channel column j,
+    // i.e. 8 consecutive positions: two 16-byte stores.
+    float* yb = y + b * (int64_t)Cout * ldy;
+    const float lo = relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int cn = 0; cn < CN; ++cn) {
+        const int co = m0 + wm * 64 + cn * 32 + j;
+        if (co >= Cout) continue;
+        float* yr = yb + (int64_t)co * ldy;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rq + e;
+                const float m0v = acc[0][cn][r], m1 = acc[1][cn][r], m2 = acc[2][cn][r], m3 = acc[3][cn][r];
+                o[2 * e] = fmaxf(((m0v + m1) + m2) + bv[cn], lo);
+                o[2 * e + 1] = fmaxf(((m1 - m2) - m3) + bv[cn], lo);
+            }
+            const int p = p0 + 2 * (wn * 32 + 8 * rq + 4 * h);
+            if constexpr (VEC == 4) {
+                if (p < Lout) *reinterpret_cast<float4*>(yr + p) = make_float4(o[0], o[1], o[2], o[3]);
+                if (p + 4 < Lout) *reinterpret_cast<float4*>(yr + p + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (p + e < Lout) yr[p + e] = o[e];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- generic path
 constexpr int GBM = 64, GKC = 32;
 constexpr int GLDA = GKC + 4;
@@ -361,6 +559,24 @@ int launch_tile(const float* x, const float* w, const float* bias, float* y, int
     return lbm::check_launch("lbm_conv1d_f32");
 }
 
+int launch_wino3(const float* x, const float* w, const float* bias, float* y, int64_t B, int Cin, int Lin, int64_t ldx, int Cout,
+                 int Lout, int64_t ldy, int relu, hipStream_t st) {
+    const int ptiles = (Lout + BN - 1) / BN;
+    const int mtiles = (Cout + WinoCfg::BM - 1) / WinoCfg::BM;
+    const int64_t blocks = B * ptiles * mtiles;
+    if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_conv1d_f32: grid too large");
+    const size_t lds = WinoCfg::LDS_FLOATS * sizeof(float);
+    const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && ldx >= 4 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    auto k = vec ? conv_wino3_kernel<4> : conv_wino3_kernel<1>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_conv1d_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, w, bias, y, Cin, Lin, (int)ldx, Cout, Lout, (int)ldy,
+                       relu, ptiles, mtiles);
+    return lbm::check_launch("lbm_conv1d_f32");
+}
+
 }  // namespace
 
 extern "C" int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
@@ -382,6 +598,8 @@ extern "C" int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* 
     if (w_vec && Cin >= ck && pad <= (ksize == 1 ? 0 : 4)) {
         if (ksize == 4 && stride == 2 && Cout <= 64) return launch_tile<4, 2, 64>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 4 && stride == 2) return launch_tile<4, 2, 128>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
+        if (ksize == 3 && stride == 1 && pad == 1 && Cin % 8 == 0 && Cout >= 64)   // Winograd F(2,3): 2/3 of the MFMA work
+            return launch_wino3(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, relu, st);
         if (ksize == 3 && stride == 1 && Cin % 4 == 0 && Cout >= 256) return launch_tile<3, 1, 256>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 1 && stride == 1 && Cout >= 256) return launch_tile<1, 1, 256>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 3 && stride == 1 && Cin % 4 == 0) return launch_tile<3, 1, 128>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
