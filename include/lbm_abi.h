@@ -73,6 +73,26 @@ int lbm_fir_fft_f32(const float* x, float* y, int64_t rows, int32_t T, const voi
 int lbm_affine_ch_f32(const float* x, float* y, int64_t E, int32_t Cin, int32_t Cout, int32_t T,
                       const float* A, const float* b, lbm_stream_t stream);
 
+/* ---- 8(f)-3: ICA fit -- FastICA fixed-point statistics -------------------------------------------------
+ * Replaces the per-iteration pass over the data inside ICA(method='fastica').fit(raw) at
+ * training/preprocess.py:91-98, multi-train/withpsd.py:127-130, preprocessing_unsupervised.py:39-40 (MNE
+ * hands the PCA-whitened recording to sklearn FastICA(whiten=False); its `_ica_par` loop body is
+ *   gwtx, g_wtx = g(W X);  W1 = sym_decorrelation(gwtx X^T / T - g_wtx[:, None] * W)):
+ *   y = W z,  gxt[i, j] = sum_t fun(y_i(t)) z_j(t),  gsum[i] = sum_t fun'(y_i(t))
+ * z: [n, T] float32 with row pitch ldz (the whitened recording); W: [n, n] float32 row-major;
+ * gxt: [n, n] and gsum: [n] float64 outputs (sums, not means), reduced in a fixed order (deterministic).
+ * fun: LBM_ICA_FUN_LOGCOSH (tanh(alpha y); sklearn default), _EXP, _CUBE, or _IDENTITY (fun(y) = y and
+ * gsum = sum_t y: with W = I this is the second-moment + sum pass of the PCA whitening step).
+ * n <= 64.  workspace: lbm_ica_stats_workspace_bytes(T, n) bytes of device scratch.  The small n x n
+ * algebra between passes (symmetric decorrelation, convergence test) stays on the host (lbm_amd/ica.py). */
+#define LBM_ICA_FUN_LOGCOSH 0
+#define LBM_ICA_FUN_EXP 1
+#define LBM_ICA_FUN_CUBE 2
+#define LBM_ICA_FUN_IDENTITY 3
+size_t lbm_ica_stats_workspace_bytes(int64_t T, int32_t n);
+int lbm_ica_stats_f32(const float* z, int64_t ldz, int64_t T, int32_t n, const float* W, int32_t fun, float alpha,
+                      double* gxt, double* gsum, void* workspace, lbm_stream_t stream);
+
 /* ---- a4 (slicing): epochs from a continuous recording ------------------------------------------------
  * Replaces the window extraction of mne.Epochs(raw, events, tmin, tmax) at training/preprocess.py:262-271,
  * multi-train/withpsd.py:213-216: out[e, c, t] = raw[c, starts[e] + t], t < Tw.  raw: [C, Trec] with row

@@ -277,6 +277,103 @@ def average_reference_matrix(C: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# 8(f)-3: ICA fit (MNE ICA._fit glue restated; the FastICA loop is sklearn's, the back-end MNE calls)
+# --------------------------------------------------------------------------------------
+
+def _exp_var_ncomp(var, n):
+    cvar = np.asarray(var, dtype=np.float64).cumsum()
+    cvar /= cvar[-1]
+    k = min(int((cvar <= n).sum()) + 1, len(cvar))
+    return k, float(cvar[k - 1])
+
+
+def ica_fit(data, n_components=None, random_state=97, max_iter=1000, tol=1e-4, fun="logcosh") -> dict:
+    """``ICA(n_components, method='fastica', random_state=97, max_iter='auto').fit`` on a ``[C, T]`` float64
+    array (training/preprocess.py:91-98, multi-train/withpsd.py:127-130): scalar pre-whitener, PCA by SVD with
+    ``svd_flip`` and whitening, ``sklearn.decomposition.FastICA(whiten=False)``, un-whitening of the unmixing
+    matrix, ``pinv`` mixing, components sorted by explained variance.  MNE-side glue: parity unpinned."""
+    from sklearn.decomposition import FastICA
+    x = np.asarray(data, dtype=np.float64)
+    C, T = x.shape
+    pre = float(np.std(x))
+    pre = pre if pre != 0 else 1.0
+    xw = x / pre
+    mean = xw.mean(axis=1)
+    X = (xw - mean[:, None]).T                                    # [T, C]
+    U, S, V = np.linalg.svd(X, full_matrices=False)
+    mx = np.argmax(np.abs(U), axis=0)                             # svd_flip, u-based
+    signs = np.sign(U[mx, np.arange(U.shape[1])])
+    signs[signs == 0] = 1.0
+    U, V = U * signs, V * signs[:, None]
+    ev = S ** 2 / (T - 1)
+    ratio = ev / ev.sum()
+    if n_components is None:
+        n = _exp_var_ncomp(ratio, 0.999999)[0]
+    elif isinstance(n_components, float):
+        n = _exp_var_ncomp(ratio, n_components)[0]
+    else:
+        n = int(n_components)
+    Z = U[:, :n] * math.sqrt(T - 1)                               # whitened data [T, n]
+    ica = FastICA(whiten=False, random_state=np.random.RandomState(random_state), max_iter=max_iter, tol=tol, fun=fun)
+    ica.fit(Z)
+    W = ica.components_
+    norms = np.sqrt(ev[:n])
+    norms[norms == 0] = 1.0
+    unmixing = W / norms[None, :]
+    mixing = np.linalg.pinv(unmixing)
+    src = unmixing @ (V[:n] @ X.T)
+    var = (mixing ** 2).sum(axis=0) * (src ** 2).sum(axis=1) / (n * T - 1)
+    srt = np.argsort(var)[::-1]
+    return dict(unmixing=unmixing[srt, :], mixing=mixing[:, srt], pca_components=V, pca_mean=mean,
+                pre_whitener=np.full((C, 1), pre), n_components=n, pca_explained_variance=ev, n_iter=int(ica.n_iter_),
+                exclude=[], W=W[srt, :], Z=Z)
+
+
+def fastica_stats(z, W, fun="logcosh", alpha=1.0):
+    """One ``_ica_par`` pass in float64: (sum_t g(y) z^T, sum_t g'(y)), y = W z, z [n, T]."""
+    z = np.asarray(z, dtype=np.float64)
+    y = np.asarray(W, dtype=np.float64) @ z
+    if fun == "logcosh":
+        g = np.tanh(alpha * y)
+        gp = alpha * (1.0 - g ** 2)
+    elif fun == "exp":
+        e = np.exp(-0.5 * y ** 2)
+        g, gp = y * e, (1.0 - y ** 2) * e
+    elif fun == "cube":
+        g, gp = y ** 3, 3.0 * y ** 2
+    else:
+        g, gp = y, y
+    return g @ z.T, gp.sum(axis=1)
+
+
+def find_outliers(X, threshold=3.0, max_iter=2):
+    """mne.preprocessing.bads._find_outliers (tail=0): iterative |zscore| > threshold on the unmasked entries."""
+    from scipy.stats import zscore
+    X = np.asarray(X, dtype=np.float64)
+    mask = np.zeros(len(X), dtype=bool)
+    for _ in range(max_iter):
+        Xm = np.ma.masked_array(X, mask)
+        this_z = np.abs(zscore(Xm))
+        local_bad = np.asarray(np.ma.filled(this_z > threshold, False))
+        mask = np.max([mask, local_bad], 0)
+        if not np.any(local_bad):
+            break
+    return np.where(mask)[0]
+
+
+def find_bads_eog(ica: dict, data, eog, sfreq, threshold=3.0, l_freq=1.0, h_freq=10.0):
+    """``ica.find_bads_eog`` (training/preprocess.py:108): Pearson correlation of the 1-10 Hz sources with the 1-10 Hz
+    EOG signal, outliers by iterative z-score, ordered by |score|."""
+    src = ica_sources(data, ica["unmixing"], ica["pca_components"], ica["pca_mean"], ica["pre_whitener"], ica["n_components"])
+    src = filter_data(src, sfreq, l_freq, h_freq)
+    tgt = filter_data(np.asarray(eog, dtype=np.float64)[None, :], sfreq, l_freq, h_freq)[0]
+    scores = np.array([np.corrcoef(s, tgt)[0, 1] for s in src])
+    bad = find_outliers(scores, threshold)
+    bad = bad[np.argsort(np.abs(scores[bad]))[::-1]]
+    return [int(i) for i in bad], scores
+
+
+# --------------------------------------------------------------------------------------
 # a4-a6: epoch post-processing
 # --------------------------------------------------------------------------------------
 

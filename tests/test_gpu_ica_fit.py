@@ -1,0 +1,110 @@
+"""GPU parity tests of the ICA fit path: lbm_ica_stats_f32 through the C ABI vs the float64
+oracle, and lbm_amd.ica_fit / find_bads_eog vs the oracle's restatement (sklearn FastICA is the loop's reference).
+
+Tolerances: the statistics are sums of O(1) terms over T samples; fp32 partial sums over <= 8192 samples and the
+fast exp give |err| <= 2e-5 * (T * scale).  The fitted matrices are compared at 1e-3 relative (the fixed-point
+iteration stops at tol 1e-4 on 1 - |cos| of the update, i.e. the reference itself is only converged to ~1e-2 rad;
+the GPU run follows the same trajectory, same iteration count, to fp32 rounding).
+"""
+import numpy as np
+import pytest
+import torch
+
+import lbm_amd
+from lbm_amd import _lib, fastica as fit
+from oracle import eeg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mixture(C, T, seed=3, scale=1e-5, offset=3e-6):
+    rng = np.random.RandomState(seed)
+    t = np.arange(T) / 500.0
+    base = [rng.laplace(size=T), rng.uniform(-1, 1, T), np.sign(np.sin(2 * np.pi * 3 * t)), np.sin(2 * np.pi * 11 * t + 0.3),
+            rng.laplace(size=T) ** 3, ((t * 7) % 1) - 0.5]
+    S = np.stack((base + [rng.laplace(size=T) * rng.uniform(0.5, 2) for _ in range(max(C - 6, 0))])[:C])
+    A = rng.normal(size=(C, C))
+    return (A @ S) * scale + offset, S
+
+
+@pytest.mark.parametrize("fun", ["logcosh", "exp", "cube", "identity"])
+@pytest.mark.parametrize("n,T,pitch", [(30, 40001, 40004), (5, 31, 31), (32, 1000, 1000), (33, 4097, 4100), (64, 20000, 20000),
+                                       (1, 100, 100)])
+def test_ica_stats_match_float64(n, T, pitch, fun):
+    rng = np.random.RandomState(n + T)
+    z = rng.laplace(size=(n, T)).astype(np.float32)
+    W = rng.normal(size=(n, n)) / np.sqrt(n)
+    buf = torch.full((n, pitch), float("nan"), device=DEV)        # pitch padding must never be read into the sums
+    buf[:, :T] = torch.from_numpy(z)
+    gxt, gsum = fit.ica_stats(buf, W, fun=fun, alpha=1.0, T=T)
+    W32 = W.astype(np.float32).astype(np.float64)
+    want_gxt, want_gsum = orc.fastica_stats(z, W32, fun=fun)
+    y = W32 @ z.astype(np.float64)
+    g_scale = {"logcosh": 1.0, "exp": 1.0, "cube": float(np.abs(y).max() ** 3), "identity": float(np.abs(y).max())}[fun]
+    gp_scale = {"logcosh": 1.0, "exp": 1.0, "cube": float(3 * np.abs(y).max() ** 2), "identity": float(np.abs(y).max())}[fun]
+    assert np.abs(gxt - want_gxt).max() <= 2e-5 * T * g_scale
+    assert np.abs(gsum - want_gsum).max() <= 2e-5 * T * gp_scale
+    # deterministic: a second run gives the same bits
+    gxt2, gsum2 = fit.ica_stats(buf, W, fun=fun, alpha=1.0, T=T)
+    assert np.array_equal(gxt, gxt2) and np.array_equal(gsum, gsum2)
+
+
+def test_ica_stats_rejects_bad_arguments():
+    z = torch.zeros(65, 100, device=DEV)
+    with pytest.raises(ValueError):
+        fit.ica_stats(z, np.eye(65))
+    lib = _lib.load()
+    assert lib.lbm_ica_stats_workspace_bytes(100, 65) == 0
+    assert lib.lbm_ica_stats_f32(None, 0, 10, 4, None, 0, 1.0, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("C,T,ncomp", [(12, 40000, None), (30, 60000, None), (30, 30000, 20), (12, 20000, 0.95)])
+def test_ica_fit_matches_oracle(C, T, ncomp):
+    x, _ = _mixture(C, T)
+    ref = orc.ica_fit(x, n_components=ncomp)
+    got = lbm_amd.ica_fit(torch.from_numpy(x).to(DEV, torch.float32), n_components=ncomp)
+    assert got["n_components"] == ref["n_components"]
+    assert got["n_iter"] == ref["n_iter"]
+    assert abs(float(got["pre_whitener"][0, 0]) / float(ref["pre_whitener"][0, 0]) - 1) < 1e-5
+    for k, tol in [("pca_explained_variance", 1e-4), ("pca_components", 1e-3), ("unmixing", 1e-3), ("mixing", 1e-3)]:
+        a, b = np.asarray(got[k], dtype=np.float64), np.asarray(ref[k], dtype=np.float64)
+        assert a.shape == b.shape, k
+        assert np.abs(a - b).max() <= tol * np.abs(b).max(), (k, np.abs(a - b).max() / np.abs(b).max())
+    # the fitted state drives ica_apply: removing component 0 on the GPU == the oracle's apply with the oracle's fit
+    keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")
+    y = lbm_amd.ica_apply(torch.from_numpy(x[None]).to(DEV, torch.float32), exclude=[0], **{k: got[k] for k in keys})[0].cpu().numpy()
+    want = orc.ica_apply(x, *(ref[k] for k in keys), exclude=[0])
+    assert np.abs(y - want).max() <= 1e-3 * np.abs(want).max()
+
+
+def test_ica_fit_recovers_sources_and_is_deterministic():
+    x, S = _mixture(10, 50000, seed=11)
+    xd = torch.from_numpy(x).to(DEV, torch.float32)
+    a = lbm_amd.ica_fit(xd, fit_params=dict(tol=1e-9), max_iter=200)
+    b = lbm_amd.ica_fit(xd, fit_params=dict(tol=1e-9), max_iter=200)
+    assert np.array_equal(a["unmixing"], b["unmixing"]) and a["n_iter"] == b["n_iter"]
+    src = lbm_amd.ica_get_sources(xd[None], **{k: a[k] for k in ("unmixing", "pca_components", "pca_mean", "pre_whitener",
+                                                                 "n_components")})[0].cpu().numpy().astype(np.float64)
+    cc = np.abs(np.corrcoef(np.vstack([src, S]))[:10, 10:])
+    assert cc.max(axis=1).min() > 0.99, cc.max(axis=1)
+
+
+def test_find_bads_eog_matches_oracle():
+    rng = np.random.RandomState(5)
+    C, T, fs = 16, 60000, 500.0
+    x, _ = _mixture(C, T, seed=5)
+    blink = np.zeros(T)
+    for c in rng.randint(500, T - 500, size=60):                   # 0.3 s half-sine blinks
+        blink[c:c + 150] += np.sin(np.linspace(0, np.pi, 150))
+    topo = np.exp(-np.arange(C) / 3.0)                             # frontal weighting
+    x = x + 8e-5 * topo[:, None] * blink[None, :]
+    eog = 2e-4 * blink + 2e-6 * rng.randn(T)
+    ref = orc.ica_fit(x)
+    want_idx, want_scores = orc.find_bads_eog(ref, x, eog, fs)
+    xd = torch.from_numpy(x).to(DEV, torch.float32)
+    got = lbm_amd.ica_fit(xd)
+    idx, scores = lbm_amd.find_bads_eog(got, xd, torch.from_numpy(eog).to(DEV, torch.float32), fs)
+    assert len(want_idx) >= 1, "the synthetic blink component must be detectable"
+    assert idx == want_idx
+    assert np.abs(scores - want_scores).max() <= 2e-3

@@ -2,6 +2,7 @@
 """Run ONE stage of the pipeline repeatedly on resident synthetic data (for rocprofv3 --pmc / --kernel-trace).
 
     python tools/kbench.py --stage vq|conv1|conv2|conv3|conv4|fir|fir_direct|affine|post|welch --epochs 16384 --reps 5
+    python tools/kbench.py --stage ica_stats|ica_fit --cin 30 --samples 1800000     (one hour of 500 Hz EEG)
 Prints the HIP-event average per launch.
 """
 import argparse
@@ -24,6 +25,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dense", action="store_true", help="conv stages: dense rows (pitch = length) instead of 16-byte rows")
+    ap.add_argument("--samples", type=int, default=1_800_000, help="ica stages: recording length")
     ap.add_argument("--cin", type=int, default=0, help="conv stages: override the input channel count (random weights)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -36,10 +38,39 @@ def main():
     rnd = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
     L1, S = 750, 375
     s = args.stage
-    if s in ("fir", "fir_direct", "affine", "post", "welch"):
+    if s in ("ica_stats", "ica_fit"):
+        import time
+        from lbm_amd import fastica
+        n, Tr = args.cin or 30, args.samples
+        rs = np.random.RandomState(0)
+        src = torch.distributions.Laplace(0.0, 1.0).sample((n, Tr)).to(dev)
+        rec = (torch.from_numpy(rs.normal(size=(n, n))).to(dev, torch.float32) @ src) * 1e-5
+        if s == "ica_fit":
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = lbm_amd.ica_fit(rec)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"ica_fit: {dt * 1e3:.1f} ms for [{n} x {Tr}] ({got['n_iter']} iterations, n_components={got['n_components']})")
+            if Tr <= 400_000:
+                from oracle import eeg_oracle as orc
+                xh = rec.cpu().numpy().astype(np.float64)
+                t0 = time.perf_counter()
+                ref = orc.ica_fit(xh)
+                print(f"cpu oracle (numpy SVD + sklearn FastICA): {(time.perf_counter() - t0) * 1e3:.1f} ms ({ref['n_iter']} iterations)")
+            return
+        lib2 = _lib.load()
+        Wd = torch.from_numpy(rs.normal(size=(n, n)) / np.sqrt(n)).to(dev, torch.float32).contiguous()
+        out = torch.empty(n * n + n, dtype=torch.float64, device=dev)
+        ws = torch.empty(lib2.lbm_ica_stats_workspace_bytes(Tr, n), dtype=torch.uint8, device=dev)
+        zz = src.contiguous()
+        fn = lambda: lib2.lbm_ica_stats_f32(p(zz), Tr, Tr, n, p(Wd), 0, 1.0, p(out), p(out[n * n:]), p(ws), st)  # noqa: E731
+    elif s in ("fir", "fir_direct", "affine", "post", "welch"):
         x = synth_epochs(E, C, T, seed=3, device=dev, chunk=2048)
         y = torch.empty_like(x)
-    if s == "vq":
+    if s in ("ica_stats",):
+        pass
+    elif s == "vq":
         PS = (S + 3) & ~3
         z = rnd(E, 256, PS)
         cb = w["vq_layer.embedding.weight"].contiguous()
@@ -97,6 +128,8 @@ def main():
     extra = ""
     if s.startswith("conv"):
         extra = f", {2.0 * cout * cin * ks * lout * E / (ms * 1e-3) / 1e12:.1f} TFLOP/s"
+    if s == "ica_stats":
+        extra = f", {args.samples * (args.cin or 30) * 4 / (ms * 1e-3) / 1e12:.2f} TB/s of the recording"
     print(f"{s}: {ms:.4f} ms per launch ({E} epochs{extra})")
 
 
