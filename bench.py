@@ -32,7 +32,7 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_fold_kernel",
                    "bandpower": "bandpower_kernel", "conv1": "conv_tile_kernel<4,2,64>", "conv2": "conv_tile_kernel<4,2,128>",
-                   "conv3": "conv_tile_kernel<3,1,128>", "conv4": "conv_tile_kernel<1,1,128>", "vq": "vq_argmin_kernel"}
+                   "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1,1,256>", "vq": "vq_argmin_kernel"}
 
 
 def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048):
@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--fold-proj", action="store_true",
+                    help="non-default variant: tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook "
+                         "(PipelineConfig.fold_projection; no z tensor; equal tokens except fp32 near-ties)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 control flow on a box "
                          "with fewer GPUs than ranks (ranks share devices, collectives staged through host memory)")
@@ -130,7 +133,8 @@ def main():
         from lbm_amd.synth import synth_encoder
         weights = synth_encoder(C)
     codebook = weights["vq_layer.embedding.weight"] if (K == 512 and args.shape == "S") else synth_codebook(K, D)
-    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1)
+    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1,
+                                 fold_projection=args.fold_proj)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -243,7 +247,7 @@ def main():
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K,
+                       "codebook": K, "fold_projection": bool(args.fold_proj),
                        "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,

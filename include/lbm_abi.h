@@ -191,9 +191,15 @@ int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* w, const fl
  *   [b][d] rows of z (element (n, d) is x[(b*D + d)*ldx + s]).  S is ignored for LBM_VQ_ROWS.
  * codebook: [K, D]; e_sqnorm: [K] = lbm_rownorm2_f32(codebook); idx_out: [N] int64;
  * mind_or_null: [N] minimum distance; hist_or_null: [K] usage counts, ADDED to (caller zeroes).
- * D must be a multiple of 8 and <= 256; K >= 1. */
+ * D must be a multiple of 8 and <= 256; K >= 1.
+ * layout | LBM_VQ_NO_XNORM: the per-row constant sum(x_n^2) is left out (score[n,k] = e_sqnorm[k] - 2 x_n . e_k;
+ *   same argmin in exact arithmetic, mind holds the score).  For a codebook folded through the encoder's last
+ *   1x1 convolution: with z = W h + b, d[n,k] - |z_n|^2 = (|e_k|^2 - 2 b.e_k) - 2 h_n.(W^T e_k),
+ *   so tokens follow from h directly with codebook' = E W and e_sqnorm' = |e|^2 - 2 E b
+ *   (lbm_amd.quantizer.fold_projection); tokens then differ from the unfolded path only at fp32 near-ties. */
 #define LBM_VQ_ROWS 0
 #define LBM_VQ_CHANNEL_MAJOR 1
+#define LBM_VQ_NO_XNORM 2
 int lbm_rownorm2_f32(const float* m, float* out, int64_t rows, int32_t D, lbm_stream_t stream);
 int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const float* codebook,
                       const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,

@@ -19,7 +19,7 @@ PAD_REFLECT_LIMITED, PAD_ZERO = 0, 1
 STD_NONE, STD_EPOCH_CHANNEL = 0, 1
 WIN_BOXCAR, WIN_HANN, WIN_HAMMING = 0, 1, 2
 AVG_MEAN, AVG_MEDIAN, AVG_NONE = 0, 1, 2
-VQ_ROWS, VQ_CHANNEL_MAJOR = 0, 1
+VQ_ROWS, VQ_CHANNEL_MAJOR, VQ_NO_XNORM = 0, 1, 2
 
 _p, _i64, _i32, _f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 

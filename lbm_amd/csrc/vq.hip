@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
                                                                 const float* __restrict__ codebook,
                                                                 const float* __restrict__ e_sqnorm,
                                                                 int64_t* __restrict__ idx_out, float* __restrict__ mind,
-                                                                int64_t N, int D, int K, int vec_ok, int64_t S) {
+                                                                int64_t N, int D, int K, int vec_ok, int64_t S, int no_xnorm) {
     constexpr int HALF = DP / 2;
     constexpr int LDE = DP + 4;
     extern __shared__ __align__(16) float smem[];
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
 #pragma unroll
     for (int s = 0; s < HALF; ++s) xx = fmaf(bx[s], bx[s], xx);
     xx += __shfl_xor(xx, 32, 64);
+    if (no_xnorm) xx = 0.f;   // folded codebooks: the row constant is dropped (finer rounding grid for the scores)
 
     float best = INFINITY;
     int bidx = 0;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void perplexity_kernel(const unsigned long lon
 }
 
 template <int DP>
-int launch_vq(const float* x, int64_t ldx, int layout, int64_t S, const float* codebook, const float* e_sqnorm, int64_t* idx_out,
+int launch_vq(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, const float* codebook, const float* e_sqnorm, int64_t* idx_out,
               float* mind, int64_t N, int D, int K, hipStream_t st) {
     const size_t lds = ((size_t)kTileCodes * (DP + 4) + kTileCodes) * sizeof(float);
     const int64_t blocks = (N + kRowsPerBlock - 1) / kRowsPerBlock;
@@ -236,12 +237,12 @@ int launch_vq(const float* x, int64_t ldx, int layout, int64_t S, const float* c
         auto k = vq_argmin_kernel<DP, LBM_VQ_ROWS>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S, no_xnorm);
     } else {
         auto k = vq_argmin_kernel<DP, LBM_VQ_CHANNEL_MAJOR>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S, no_xnorm);
     }
     return lbm::check_launch("lbm_vq_argmin_f32");
 }
@@ -264,7 +265,9 @@ extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, in
     LBM_REQUIRE(N >= 0, LBM_EINVAL, "lbm_vq_argmin_f32: negative N");
     LBM_REQUIRE(D >= 8 && D <= 256 && (D & 7) == 0, LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: D=%d must be a multiple of 8 in [8,256]", D);
     LBM_REQUIRE(K >= 1, LBM_EINVAL, "lbm_vq_argmin_f32: K must be >= 1");
-    LBM_REQUIRE(layout == LBM_VQ_ROWS || layout == LBM_VQ_CHANNEL_MAJOR, LBM_EINVAL, "lbm_vq_argmin_f32: unknown layout %d", layout);
+    LBM_REQUIRE(layout >= 0 && layout <= (LBM_VQ_CHANNEL_MAJOR | LBM_VQ_NO_XNORM), LBM_EINVAL, "lbm_vq_argmin_f32: unknown layout %d", layout);
+    const int no_xnorm = (layout & LBM_VQ_NO_XNORM) ? 1 : 0;
+    layout &= ~LBM_VQ_NO_XNORM;
     if (N == 0) return LBM_OK;
     LBM_REQUIRE(x && codebook && e_sqnorm && idx_out, LBM_EINVAL, "lbm_vq_argmin_f32: NULL pointer");
     LBM_REQUIRE(((uintptr_t)codebook & 15) == 0, LBM_EINVAL, "lbm_vq_argmin_f32: codebook must be 16-byte aligned");
@@ -276,9 +279,9 @@ extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, in
                     (long long)S, (long long)ldx);
     hipStream_t st = lbm::as_stream(stream);
     int rc;
-    if (D <= 64) rc = launch_vq<64>(x, ldx, layout, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
-    else if (D <= 128) rc = launch_vq<128>(x, ldx, layout, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
-    else rc = launch_vq<256>(x, ldx, layout, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    if (D <= 64) rc = launch_vq<64>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else if (D <= 128) rc = launch_vq<128>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else rc = launch_vq<256>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
     if (rc != LBM_OK) return rc;
     if (hist_or_null != nullptr) {
         LBM_REQUIRE(K <= 32768, LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: histogram supports K <= 32768");

@@ -36,6 +36,8 @@ class PipelineConfig:
     do_filter: bool = True
     do_ica: bool = True
     fir_method: str = "fft"            # 'fft' (fast convolution) or 'direct' (LDS direct form)
+    fold_projection: bool = False      # tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook
+                                       # (quantizer.fold_projection; no z output; equal tokens except fp32 near-ties)
 
 
 class EpochPipeline:
@@ -66,6 +68,10 @@ class EpochPipeline:
             self.K, self.D = self.codebook.shape
             self.ee = torch.empty((self.K,), dtype=torch.float32, device=self.dev)
             _lib.check(self.lib.lbm_rownorm2_f32(_lib.ptr(self.codebook), _lib.ptr(self.ee), self.K, self.D, _lib.stream_ptr()))
+            self.cb_fold = self.ee_fold = None
+            if cfg.fold_projection:
+                from .quantizer import fold_projection
+                self.cb_fold, self.ee_fold = fold_projection(self.codebook, self.enc["encoder.6.weight"], self.enc["encoder.6.bias"])
             T = cfg.n_times
             self.L1 = (T + 2 - 4) // 2 + 1
             self.L2 = (self.L1 + 2 - 4) // 2 + 1
@@ -86,8 +92,10 @@ class EpochPipeline:
              "psd": mk(E, c.n_channels, self.F), "bp": mk(E, 6)}
         if c.do_tokenize:
             # encoder activations: rows padded to a multiple of 4 floats, so every conv access is a 16-byte one
-            B.update(h1=mk(E, 64, self.P1), h2=mk(E, 128, self.P2), h3=mk(E, 256, self.P2), z=mk(E, self.D, self.P2),
+            B.update(h1=mk(E, 64, self.P1), h2=mk(E, 128, self.P2), h3=mk(E, 256, self.P2),
                      tokens=mk(E, self.S, dt=torch.int64), hist=torch.zeros((self.K,), dtype=torch.int64, device=d))
+            if not c.fold_projection:
+                B.update(z=mk(E, self.D, self.P2))
         self._buf, self._cap = B, E
 
     def reset_hist(self):
@@ -153,6 +161,13 @@ class EpochPipeline:
             t0 = mark("conv2", t0)
             conv(B["h2"], self.P2, B["h3"], self.P2, 4, 128, self.L2, 256, 3, 1, 1, 1)
             t0 = mark("conv3", t0)
+            if c.fold_projection:
+                _lib.check(lib.lbm_vq_argmin_f32(p(B["h3"]), self.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, self.S, p(self.cb_fold),
+                                                 p(self.ee_fold), p(B["tokens"]), None, p(B["hist"]), E * self.S,
+                                                 self.cb_fold.shape[1], self.K, st), "vq(folded)")
+                t0 = mark("vq", t0)
+                out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"])
+                return out
             conv(B["h3"], self.P2, B["z"], self.P2, 6, 256, self.L2, self.D, 1, 1, 0, 0)
             t0 = mark("conv4", t0)
             _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.codebook), p(self.ee),

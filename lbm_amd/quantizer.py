@@ -25,8 +25,27 @@ def rownorm2(m: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def fold_projection(codebook, proj_weight, proj_bias=None):
+    """Fold the encoder's last 1x1 convolution (training/model.py:176, no activation after it) into the codebook.
+
+    With z = W h + b:  |z - e_k|^2 - |z|^2 = (|e_k|^2 - 2 b.e_k) - 2 h.(W^T e_k), so the tokens of ``VQVAE.encode``
+    follow from the third layer's output h with ``codebook' = E W`` and ``e_sqnorm' = |e|^2 - 2 E b`` (float64 on the
+    host, rounded once) and ``vq_argmin(h, codebook', e_sqnorm', no_xnorm=True)`` -- the 256x256 projection GEMM
+    and the z tensor disappear.  Tokens differ from the unfolded path only at fp32 near-ties.
+    Returns ``(codebook' [K, Cin], e_sqnorm' [K])`` as float32 tensors on the codebook's device.
+    """
+    E = codebook.detach().to(torch.float64)
+    W = proj_weight.detach().to(torch.float64).reshape(proj_weight.shape[0], -1)        # [D, Cin] (ksize 1)
+    if W.shape[0] != E.shape[1]:
+        raise ValueError(f"projection has {W.shape[0]} output channels, codebook dim is {E.shape[1]}")
+    c = (E * E).sum(dim=1)
+    if proj_bias is not None:
+        c = c - 2.0 * (E @ proj_bias.detach().to(torch.float64))
+    return (E @ W).to(torch.float32).contiguous(), c.to(torch.float32).contiguous()
+
+
 def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = None, *, channel_major: bool = False,
-              return_min: bool = False, hist: torch.Tensor = None):
+              return_min: bool = False, hist: torch.Tensor = None, no_xnorm: bool = False):
     """Nearest-code indices (int64).
 
     x: [N, D] rows (any row stride that is a multiple of 1 float), or with ``channel_major`` the encoder
@@ -57,6 +76,8 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
     mind = torch.empty((N,), dtype=torch.float32, device=x.device) if return_min else None
     if hist is not None and (hist.dtype != torch.int64 or hist.numel() != K or not hist.is_contiguous()):
         raise ValueError("hist must be a contiguous int64 tensor of K entries")
+    if no_xnorm:
+        layout |= _lib.VQ_NO_XNORM
     _lib.check(_lib.load().lbm_vq_argmin_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(cb), _lib.ptr(e_sqnorm), _lib.ptr(idx),
                                              _lib.ptr(mind), _lib.ptr(hist), N, D, K, _lib.stream_ptr()), "lbm_vq_argmin_f32")
     return (idx, mind) if return_min else idx

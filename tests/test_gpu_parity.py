@@ -459,6 +459,36 @@ def test_pipeline_matches_oracle(shipped, T):
     assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
 
 
+@pytest.mark.parametrize("codebook", ["shipped", "random"])
+def test_pipeline_folded_projection_tokens(shipped, vq_golden, codebook):
+    """the last 1x1 convolution folded into the codebook (fold_projection) gives the tokens of the
+    unfolded path; a mismatch must be a documented near-tie of the unfolded path's own z (same 8-eps rule)."""
+    cb = shipped["vq_layer.embedding.weight"] if codebook == "shipped" else np.asarray(synth_codebook(512, 256)) * 0.3
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    mk = lambda fold: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=fold), taps, A, b, shipped, cb)  # noqa: E731
+    x = (synth_epochs(96, 30, 1500, seed=21) * 2.0).to(DEV)
+    ref = mk(False).run(x)
+    tok_ref, z = ref["tokens"].cpu().numpy(), ref["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+    out = mk(True).run(x)
+    assert "z" not in out
+    tok = out["tokens"].cpu().numpy()
+    assert (tok == tok_ref).mean() >= 0.999
+    assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), tok_ref.reshape(-1)).all()
+    assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
+    if codebook == "shipped":   # the reference's own golden tokens (training/model.py:206-214 on the shipped checkpoint)
+        from lbm_amd.quantizer import encoder_forward, fold_projection, vq_argmin
+        enc = {k: torch.from_numpy(v).to(DEV) for k, v in shipped.items() if k.startswith("encoder.")}
+        xs = torch.from_numpy(vq_golden["x_S"]).to(DEV)
+        h3 = xs
+        for i, (s_, pd) in zip((0, 2, 4), ((2, 1), (2, 1), (1, 1))):
+            h3 = lbm_amd.conv1d(h3, enc[f"encoder.{i}.weight"], enc[f"encoder.{i}.bias"], stride=s_, padding=pd, relu=True)
+        cbf, eef = fold_projection(torch.from_numpy(cb).to(DEV), enc["encoder.6.weight"], enc["encoder.6.bias"])
+        tk = vq_argmin(h3, cbf, eef, channel_major=True, no_xnorm=True).view(xs.shape[0], -1).cpu().numpy()
+        zg = np.transpose(vq_golden["z_S"], (0, 2, 1)).reshape(-1, 256)
+        assert orc.vq_near_tie_ok(zg, cb, tk.reshape(-1), vq_golden["tokens_S"].reshape(-1)).all()
+
+
 def test_pipeline_config_L_matches_oracle():
     """BASELINE config 5 shape: 64 channels x 1 kHz x 10 s epochs, 1651-tap FIR, n_fft = 1000, 8192-entry codebook."""
     from lbm_amd.synth import synth_encoder
