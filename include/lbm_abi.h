@@ -205,6 +205,19 @@ int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, co
                       const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
                       unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
 
+/* Same contract on the bf16 matrix cores: every fp32 operand is cut into three bf16 pieces (exact residuals) and
+ * x.e keeps the six piece products down to 2^-18 relative, accumulated in fp32 -- as accurate against float64 as
+ * the fp32 fmaf chain above (tools/probe/bf16x_probe.hip) at 16/6 of the fp32 matrix rate.  Indices equal those of
+ * lbm_vq_argmin_f32 except at fp32 near-ties (SURVEY.md 8(a) rule).  The codebook is passed pre-split:
+ * lbm_vq_split_tables_bytes(K, D) sizes a caller-owned, 16-byte aligned device table that
+ * lbm_vq_split_tables_init fills from the fp32 codebook [K, D] (0 bytes = unsupported shape).  1 <= D <= 256, any K >= 1.
+ * e_sqnorm as above (lbm_rownorm2_f32 of the fp32 codebook, or the folded constants with LBM_VQ_NO_XNORM). */
+size_t lbm_vq_split_tables_bytes(int32_t K, int32_t D);
+int lbm_vq_split_tables_init(void* tables, const float* codebook, int32_t K, int32_t D, lbm_stream_t stream);
+int lbm_vq_argmin_bf16x6_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const void* tables,
+                             const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
+                             unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
+
 /* VectorQuantizerEMA.forward tail, training/model.py:100,130-139: quantized = E[idx] (returned with the
  * straight-through arithmetic x + (E[idx] - x)), sq_err_sum[0] += sum((E[idx] - x)^2) in float64
  * (caller zeroes; mse = sq_err_sum / (N*D); loss = (1 + commitment_cost) * mse in the forward pass). */

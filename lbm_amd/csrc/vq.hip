@@ -249,6 +249,14 @@ int launch_vq(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, 
 
 }  // namespace
 
+// shared with vq_bf16.hip
+int lbm_vq_hist_launch(const int64_t* idx, unsigned long long* hist, int64_t N, int K, hipStream_t st) {
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)blocks), dim3(256), (size_t)K * sizeof(unsigned int), st, idx, hist, N, K);
+    return lbm::check_launch("lbm_vq_argmin(hist)");
+}
+
 extern "C" int lbm_rownorm2_f32(const float* m, float* out, int64_t rows, int32_t D, lbm_stream_t stream) {
     LBM_REQUIRE(rows >= 0 && D >= 1, LBM_EINVAL, "lbm_rownorm2_f32: bad sizes");
     if (rows == 0) return LBM_OK;

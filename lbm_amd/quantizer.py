@@ -44,9 +44,26 @@ def fold_projection(codebook, proj_weight, proj_bias=None):
     return (E @ W).to(torch.float32).contiguous(), c.to(torch.float32).contiguous()
 
 
+def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
+    """Device table of the codebook cut into three bf16 pieces per value (``lbm_vq_split_tables_init``), the form
+    ``vq_argmin(..., split_tables=...)`` / ``lbm_vq_argmin_bf16x6_f32`` consume."""
+    cb = _lib.dev_f32(codebook)
+    K, D = cb.shape
+    lib = _lib.load()
+    nbytes = lib.lbm_vq_split_tables_bytes(K, D)
+    if nbytes == 0:
+        raise NotImplementedError(f"vq_split_tables: unsupported codebook shape ({K}, {D}) (D <= 256)")
+    tab = torch.empty(nbytes, dtype=torch.uint8, device=cb.device)
+    _lib.check(lib.lbm_vq_split_tables_init(_lib.ptr(tab), _lib.ptr(cb), K, D, _lib.stream_ptr()), "lbm_vq_split_tables_init")
+    return tab
+
+
 def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = None, *, channel_major: bool = False,
-              return_min: bool = False, hist: torch.Tensor = None, no_xnorm: bool = False):
+              return_min: bool = False, hist: torch.Tensor = None, no_xnorm: bool = False, split_tables: torch.Tensor = None):
     """Nearest-code indices (int64).
+
+    ``split_tables`` (from ``vq_split_tables(codebook)``) selects the bf16-piece kernel (fp32-grade products on the
+    bf16 matrix cores); without it the fp32-MFMA kernel runs.
 
     x: [N, D] rows (any row stride that is a multiple of 1 float), or with ``channel_major`` the encoder
     output z[B, D, S] (N = B*S rows, no permute/contiguous copy).  ``hist`` ([K] int64/uint64 counts) is
@@ -78,6 +95,11 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
         raise ValueError("hist must be a contiguous int64 tensor of K entries")
     if no_xnorm:
         layout |= _lib.VQ_NO_XNORM
+    if split_tables is not None:
+        _lib.check(_lib.load().lbm_vq_argmin_bf16x6_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(split_tables), _lib.ptr(e_sqnorm),
+                                                        _lib.ptr(idx), _lib.ptr(mind), _lib.ptr(hist), N, D, K, _lib.stream_ptr()),
+                   "lbm_vq_argmin_bf16x6_f32")
+        return (idx, mind) if return_min else idx
     _lib.check(_lib.load().lbm_vq_argmin_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(cb), _lib.ptr(e_sqnorm), _lib.ptr(idx),
                                              _lib.ptr(mind), _lib.ptr(hist), N, D, K, _lib.stream_ptr()), "lbm_vq_argmin_f32")
     return (idx, mind) if return_min else idx

@@ -340,6 +340,54 @@ def test_vq_random_codebooks_match_oracle(N, D, K):
         assert np.array_equal(lbm_amd.vq_argmin(zp[:, :, :S], torch.from_numpy(cb).to(DEV), channel_major=True).cpu().numpy(), idx)
 
 
+@pytest.mark.parametrize("N,D,K", [(1000, 256, 512), (129, 256, 8192), (77, 64, 100), (300, 128, 65), (5, 72, 7), (128, 256, 1),
+                                   (4000, 250, 300)])
+def test_vq_bf16x6_matches_oracle_and_fp32_kernel(N, D, K):
+    """lbm_vq_argmin_bf16x6_f32 (fp32 products rebuilt from three bf16 pieces): same near-tie rule, same layouts."""
+    rs = np.random.RandomState(N + K)
+    cb = rs.randn(K, D).astype(np.float32)
+    x = (cb[rs.randint(0, K, N)] + 0.7 * rs.randn(N, D)).astype(np.float32)
+    xd, cbd = torch.from_numpy(x).to(DEV), torch.from_numpy(cb).to(DEV)
+    tab = lbm_amd.vq_split_tables(cbd)
+    hist = torch.zeros(K, dtype=torch.int64, device=DEV)
+    idx, mind = lbm_amd.vq_argmin(xd, cbd, return_min=True, hist=hist, split_tables=tab)
+    idx = idx.cpu().numpy()
+    ref = orc.vq_argmin(x, cb)
+    assert orc.vq_near_tie_ok(x, cb, idx, ref).all()
+    assert (idx == ref).mean() >= 0.99
+    d64 = orc.vq_distances_f64(x, cb)
+    np.testing.assert_allclose(mind.cpu().numpy(), d64[np.arange(N), idx], rtol=1e-4, atol=1e-3)
+    assert np.array_equal(hist.cpu().numpy(), np.bincount(idx, minlength=K))
+    if D % 8 == 0:
+        assert (idx == lbm_amd.vq_argmin(xd, cbd).cpu().numpy()).mean() >= 0.999
+    wide = torch.full((N, D + 8), float("nan"), device=DEV); wide[:, :D] = xd
+    assert np.array_equal(lbm_amd.vq_argmin(wide[:, :D], cbd, split_tables=tab).cpu().numpy(), idx)
+    if N % 5 == 0:
+        S = N // 5
+        zp = torch.full((5, D, S + 3), float("nan"), device=DEV)                      # pitched channel-major rows
+        zp[:, :, :S] = xd.view(5, S, D).permute(0, 2, 1)
+        assert np.array_equal(lbm_amd.vq_argmin(zp[:, :, :S], cbd, channel_major=True, split_tables=tab).cpu().numpy(), idx)
+
+
+def test_vq_bf16x6_golden_and_duplicates(shipped, vq_golden):
+    cb = shipped["vq_layer.embedding.weight"]
+    cbd = torch.from_numpy(cb).to(DEV)
+    tab = lbm_amd.vq_split_tables(cbd)
+    idx = lbm_amd.vq_argmin(torch.from_numpy(vq_golden["gci_in"]).to(DEV), cbd, split_tables=tab).cpu().numpy()
+    assert orc.vq_near_tie_ok(vq_golden["gci_in"], cb, idx, vq_golden["gci_idx"]).all()
+    zg = torch.from_numpy(vq_golden["z_S"]).to(DEV)
+    tk = lbm_amd.vq_argmin(zg, cbd, channel_major=True, split_tables=tab).cpu().numpy()
+    assert orc.vq_near_tie_ok(np.transpose(vq_golden["z_S"], (0, 2, 1)).reshape(-1, 256), cb, tk, vq_golden["tokens_S"].reshape(-1)).all()
+    # exact duplicate codes: the lowest index wins (piece products of equal rows are equal)
+    rs = np.random.RandomState(2)
+    c2 = rs.randn(300, 256).astype(np.float32)
+    c2[299] = c2[17]; c2[150] = c2[17]
+    x = (c2[[17, 150, 299, 5]] + 1e-3 * rs.randn(4, 256)).astype(np.float32)
+    c2d = torch.from_numpy(c2).to(DEV)
+    got = lbm_amd.vq_argmin(torch.from_numpy(x).to(DEV), c2d, split_tables=lbm_amd.vq_split_tables(c2d)).cpu().numpy()
+    assert got.tolist() == [17, 17, 17, 5]
+
+
 def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
     m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)

@@ -70,7 +70,7 @@ def main():
         y = torch.empty_like(x)
     if s in ("ica_stats",):
         pass
-    elif s == "vq":
+    elif s in ("vq", "vqb"):
         PS = (S + 3) & ~3
         z = rnd(E, 256, PS)
         cb = w["vq_layer.embedding.weight"].contiguous()
@@ -78,6 +78,9 @@ def main():
         lib.lbm_rownorm2_f32(p(cb), p(ee), 512, 256, st)
         tok = torch.empty(E, S, dtype=torch.int64, device=dev)
         fn = lambda: lib.lbm_vq_argmin_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
+        if s == "vqb":
+            tab = lbm_amd.vq_split_tables(cb)
+            fn = lambda: lib.lbm_vq_argmin_bf16x6_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(tab), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
     elif s.startswith("conv"):
         i = int(s[4]) - 1
         cin, lin, cout, ks, sd, pd, relu = [(30, 1500, 64, 4, 2, 1, 1), (64, 750, 128, 4, 2, 1, 1), (128, 375, 256, 3, 1, 1, 1),
@@ -126,6 +129,8 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.reps
     extra = ""
+    if s in ("vq", "vqb"):
+        extra = f", {2.0 * 512 * 256 * 375 * E / (ms * 1e-3) / 1e12:.1f} fp32-equivalent TFLOP/s"
     if s.startswith("conv"):
         extra = f", {2.0 * cout * cin * ks * lout * E / (ms * 1e-3) / 1e12:.1f} TFLOP/s"
     if s == "ica_stats":
