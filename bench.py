@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--vq", choices=["fp32", "bf16x6"], default="fp32",
+                    help="codebook argmin kernel: fp32 MFMA (default) or fp32 products from three bf16 pieces on the bf16 MFMA")
     ap.add_argument("--fold-proj", action="store_true",
                     help="non-default variant: tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook "
                          "(PipelineConfig.fold_projection; no z tensor; equal tokens except fp32 near-ties)")
@@ -134,7 +136,7 @@ def main():
         weights = synth_encoder(C)
     codebook = weights["vq_layer.embedding.weight"] if (K == 512 and args.shape == "S") else synth_codebook(K, D)
     cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1,
-                                 fold_projection=args.fold_proj)
+                                 fold_projection=args.fold_proj, vq_method=args.vq)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -247,7 +249,7 @@ def main():
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "fold_projection": bool(args.fold_proj),
+                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq,
                        "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -48,7 +48,8 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p1, bf16x8& p2, b
     }
 }
 
-// tab: [nst][3][Kp][16] bf16, zero beyond (K, D)
+// tab: [nst][3][Kp][16] bf16, zero beyond (K, D); the two 16-byte halves of a row are stored in the order of the
+// kernel's LDS image (swapped on odd row octets), so a stage's slab is copied to LDS linearly
 __global__ __launch_bounds__(256) void vq_split_tables_kernel(const float* __restrict__ codebook, bf16x8* __restrict__ tab, int K,
                                                               int Kp, int D, int nst) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (stage, code, half)
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void vq_split_tables_kernel(const float* __res
     bf16x8 p[3];
     split8(v, p[0], p[1], p[2]);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) tab[(((int64_t)st * 3 + q) * Kp + code) * 2 + half] = p[q];
+    for (int q = 0; q < 3; ++q) tab[(((int64_t)st * 3 + q) * Kp + code) * 2 + (half ^ ((code >> 3) & 1))] = p[q];   // LDS image order
 }
 
 template <int LAYOUT>
@@ -86,8 +87,9 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
     const int total = nsup * nst;
 
     // ---- staging roles
-    // x: thread -> (row = tid & 127, octet = tid >> 7) of the stage's 128 x 16 slice
-    const int xr = tid & 127, xo = tid >> 7;
+    // x: thread -> (row = tid / 2, octet = tid & 1) of the stage's 128 x 16 slice (8 consecutive lanes write 128
+    // contiguous bytes of the LDS image: conflict-free ds_write_b128)
+    const int xr = tid >> 1, xo = tid & 1;
     int64_t n = (int64_t)blockIdx.x * kRows + xr;
     n = n < N ? n : N - 1;
     const float* xrow;
@@ -101,7 +103,6 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
         kstride = ldx;
     }
     float xv[8];
-    u32x4 cr[6];
     float xxp = 0.f;
     const int ks = (int)kstride;                 // D * ldx < 2^31 is checked by the launcher
     const int tstep = 3 * Kp * 2;                // 16-byte chunks per stage of the table
@@ -120,17 +121,18 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
                 xv[e] = xrow[(int64_t)k * ks];
             }
         }
+    };
+    // the stage's code slab goes global -> LDS directly (no registers, no ds_write): lane-linear 1 KiB per wave-instruction
+    auto copy_codes = [&](int sup, int st, int buf) {
         const u32x4* tp = tab + (st * tstep + sup * (kSup * 2) + tid);
+        unsigned char* sb = smem + buf * kStageBytes + tid * 16;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) cr[i] = tp[(i >> 1) * (Kp * 2) + (i & 1) * kThreads];   // (piece i/2, chunk tid + 256 (i&1))
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tp + (i >> 1) * (Kp * 2) + (i & 1) * kThreads),
+                                             (__attribute__((address_space(3))) void*)(sb + (i >> 1) * kCodePlane + (i & 1) * (kThreads * 16)), 16, 0, 0);
     };
     auto store_stage = [&](int sup, int st, int buf) {
         unsigned char* sb = smem + buf * kStageBytes;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int q = tid + (i & 1) * kThreads;
-            *reinterpret_cast<u32x4*>(sb + (i >> 1) * kCodePlane + swz(q >> 1, q & 1)) = cr[i];
-        }
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -216,7 +218,9 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
         }
     };
     load_stage(0, 0);
+    copy_codes(0, 0, 0);
     store_stage(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (total > 1) {
         advance();
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
             const int buf = g & 1;
             if (g + 1 < total) {   // stage g+1 (in registers since the previous iteration) -> LDS; request stage g+2
                 store_stage(rsup, rst, buf ^ 1);
+                copy_codes(rsup, rst, buf ^ 1);
                 if (g + 2 < total) {
                     advance();
                     load_stage(rsup, rst);
@@ -261,6 +266,7 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
                     }
                 zero_acc();
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stage copied by this wave has landed
             __syncthreads();
         }
     }

@@ -36,6 +36,8 @@ class PipelineConfig:
     do_filter: bool = True
     do_ica: bool = True
     fir_method: str = "fft"            # 'fft' (fast convolution) or 'direct' (LDS direct form)
+    vq_method: str = "fp32"            # 'fp32': exact fmaf chain on the fp32 MFMA; 'bf16x6': fp32 products rebuilt from three
+                                       # bf16 pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
     fold_projection: bool = False      # tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook
                                        # (quantizer.fold_projection; no z output; equal tokens except fp32 near-ties)
 
@@ -72,6 +74,12 @@ class EpochPipeline:
             if cfg.fold_projection:
                 from .quantizer import fold_projection
                 self.cb_fold, self.ee_fold = fold_projection(self.codebook, self.enc["encoder.6.weight"], self.enc["encoder.6.bias"])
+            if cfg.vq_method not in ("fp32", "bf16x6"):
+                raise ValueError(f"vq_method {cfg.vq_method!r}")
+            self.vq_tab = None
+            if cfg.vq_method == "bf16x6":
+                from .quantizer import vq_split_tables
+                self.vq_tab = vq_split_tables(self.cb_fold if cfg.fold_projection else self.codebook)
             T = cfg.n_times
             self.L1 = (T + 2 - 4) // 2 + 1
             self.L2 = (self.L1 + 2 - 4) // 2 + 1
@@ -161,17 +169,18 @@ class EpochPipeline:
             t0 = mark("conv2", t0)
             conv(B["h2"], self.P2, B["h3"], self.P2, 4, 128, self.L2, 256, 3, 1, 1, 1)
             t0 = mark("conv3", t0)
+            vq = lib.lbm_vq_argmin_f32 if self.vq_tab is None else lib.lbm_vq_argmin_bf16x6_f32
             if c.fold_projection:
-                _lib.check(lib.lbm_vq_argmin_f32(p(B["h3"]), self.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, self.S, p(self.cb_fold),
-                                                 p(self.ee_fold), p(B["tokens"]), None, p(B["hist"]), E * self.S,
-                                                 self.cb_fold.shape[1], self.K, st), "vq(folded)")
+                _lib.check(vq(p(B["h3"]), self.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, self.S,
+                              p(self.cb_fold if self.vq_tab is None else self.vq_tab), p(self.ee_fold), p(B["tokens"]), None,
+                              p(B["hist"]), E * self.S, self.cb_fold.shape[1], self.K, st), "vq(folded)")
                 t0 = mark("vq", t0)
                 out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"])
                 return out
             conv(B["h3"], self.P2, B["z"], self.P2, 6, 256, self.L2, self.D, 1, 1, 0, 0)
             t0 = mark("conv4", t0)
-            _lib.check(lib.lbm_vq_argmin_f32(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.codebook), p(self.ee),
-                                             p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
+            _lib.check(vq(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.codebook if self.vq_tab is None else self.vq_tab),
+                          p(self.ee), p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
             t0 = mark("vq", t0)
             out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"][:, :, :self.S])
         return out

@@ -507,14 +507,16 @@ def test_pipeline_matches_oracle(shipped, T):
     assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
 
 
+@pytest.mark.parametrize("vq_method", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("codebook", ["shipped", "random"])
-def test_pipeline_folded_projection_tokens(shipped, vq_golden, codebook):
+def test_pipeline_folded_projection_tokens(shipped, vq_golden, codebook, vq_method):
     """the last 1x1 convolution folded into the codebook (fold_projection) gives the tokens of the
     unfolded path; a mismatch must be a documented near-tie of the unfolded path's own z (same 8-eps rule)."""
     cb = shipped["vq_layer.embedding.weight"] if codebook == "shipped" else np.asarray(synth_codebook(512, 256)) * 0.3
     taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
     A, b = lbm_amd.ica_projection(**synth_ica(30))
-    mk = lambda fold: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=fold), taps, A, b, shipped, cb)  # noqa: E731
+    mk = lambda fold: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=fold, vq_method=vq_method if fold else "fp32"),  # noqa: E731
+                                            taps, A, b, shipped, cb)
     x = (synth_epochs(96, 30, 1500, seed=21) * 2.0).to(DEV)
     ref = mk(False).run(x)
     tok_ref, z = ref["tokens"].cpu().numpy(), ref["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
@@ -535,6 +537,22 @@ def test_pipeline_folded_projection_tokens(shipped, vq_golden, codebook):
         tk = vq_argmin(h3, cbf, eef, channel_major=True, no_xnorm=True).view(xs.shape[0], -1).cpu().numpy()
         zg = np.transpose(vq_golden["z_S"], (0, 2, 1)).reshape(-1, 256)
         assert orc.vq_near_tie_ok(zg, cb, tk.reshape(-1), vq_golden["tokens_S"].reshape(-1)).all()
+
+
+def test_pipeline_bf16x6_quantizer_tokens(shipped):
+    """The pipeline with the bf16-piece argmin kernel: tokens of the fp32-MFMA path except documented near-ties."""
+    pipe, taps, A, b = _make_pipeline(shipped, T=1500)
+    cfg = lbm_amd.PipelineConfig(vq_method="bf16x6")
+    pipe2 = lbm_amd.EpochPipeline(cfg, taps, A, b, shipped, shipped["vq_layer.embedding.weight"])
+    x = (synth_epochs(64, 30, 1500, seed=33) * 2.0).to(DEV)
+    ref = pipe.run(x)
+    tok_ref, z = ref["tokens"].cpu().numpy(), ref["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+    out = pipe2.run(x)
+    tok = out["tokens"].cpu().numpy()
+    cb = shipped["vq_layer.embedding.weight"]
+    assert (tok == tok_ref).mean() >= 0.999
+    assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
+    assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
 
 
 def test_pipeline_config_L_matches_oracle():
