@@ -8,6 +8,10 @@ NOTCH_FREQ = 60.0
 ICA_N_COMPONENTS = None
 ICA_RANDOM_STATE = 97
 ICA_METHOD = "fastica"
+AUTO_DETECT_EOG = True
+DEVIATION_CODES = [251, 252]   # training/preprocess.py:26
+RESPONSE_CODE = 253            # :27
+RT_FILTER_THRESHOLD = 0.1      # :31
 TMIN = -0.5
 TMAX = 1.5
 BASELINE = (None, 0)

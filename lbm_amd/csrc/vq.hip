@@ -75,6 +75,24 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
         // loop costs one L2 round trip per float4); clamped address + mask instead of a predicated load
         constexpr int kF4 = kTileCodes * (DP / 4) / kThreads;   // float4 per thread per tile
         constexpr int kGroup = kF4 < 8 ? kF4 : 8;
+        if (D == DP && kbase + kTileCodes <= K) {
+            // full tile: 64 x DP contiguous floats, chunk i of the tile is chunk i of the LDS image (rows padded by 4):
+            // one base address, immediate offsets, no masks (VALU slots are MFMA slots on this SIMD)
+            const float4* tile = reinterpret_cast<const float4*>(codebook + (int64_t)kbase * D) + threadIdx.x;
+#pragma unroll
+            for (int g0 = 0; g0 < kF4; g0 += kGroup) {
+                float4 stage[kGroup];
+#pragma unroll
+                for (int u = 0; u < kGroup; ++u) stage[u] = tile[(g0 + u) * kThreads];
+#pragma unroll
+                for (int u = 0; u < kGroup; ++u) {
+                    const int i = threadIdx.x + (g0 + u) * kThreads;
+                    const int code = i / (DP / 4), c4 = i - code * (DP / 4);
+                    asm volatile("" : "+v"(stage[u].x), "+v"(stage[u].y), "+v"(stage[u].z), "+v"(stage[u].w));
+                    *reinterpret_cast<float4*>(s_e + code * LDE + 4 * c4) = stage[u];
+                }
+            }
+        } else
 #pragma unroll
         for (int g0 = 0; g0 < kF4; g0 += kGroup) {
             float4 stage[kGroup];

@@ -374,6 +374,44 @@ def find_bads_eog(ica: dict, data, eog, sfreq, threshold=3.0, l_freq=1.0, h_freq
 
 
 # --------------------------------------------------------------------------------------
+# 8(f)-4: annotations -> trials -> vigilance labels (training/preprocess.py:156-259), line-by-line semantics
+# --------------------------------------------------------------------------------------
+
+def vigilance_trials(annotations, sfreq, deviation_codes=(251, 252), response_code=253, rt_filter=0.1):
+    """Returns (events [E, 3] int, labels [E] str, rts [E], alert_rt_baseline) exactly as the script builds them."""
+    ev = []
+    for onset, desc in annotations:                                     # :157-165
+        try:
+            code = int(float(desc))
+        except (ValueError, TypeError):
+            continue
+        if code in deviation_codes or code == response_code:
+            ev.append((float(onset), code))
+    ev.sort(key=lambda e: e[0])                                          # :173 (stable)
+    trials, last = [], None
+    for t, code in ev:                                                   # :180-196
+        if code in deviation_codes:
+            last = (t, code)
+        elif code == response_code:
+            if last is not None:
+                rt = t - last[0]
+                if rt >= 0:
+                    trials.append((int(round(t * sfreq)), rt))
+                last = None
+    trials = [tr for tr in trials if tr[1] >= rt_filter]                 # :204
+    rts = np.asarray([tr[1] for tr in trials], dtype=np.float64)
+    if rts.size == 0:
+        return np.zeros((0, 3), dtype=np.int64), np.asarray([], dtype="<U10"), rts, float("nan")
+    base = float(np.median(rts)) if rts.size < 5 else float(np.percentile(rts, 5))      # :216-225
+    labels = []
+    for rt in rts:                                                       # :233-236
+        labels.append("alert" if rt < 1.5 * base else ("drowsy" if rt > 2.5 * base else "transition"))
+    ids = {"alert": 1, "transition": 2, "drowsy": 3}
+    events = np.asarray([[tr[0], 0, ids[lab]] for tr, lab in zip(trials, labels)], dtype=np.int64).reshape(-1, 3)
+    return events, np.asarray(labels, dtype="<U10"), rts, base
+
+
+# --------------------------------------------------------------------------------------
 # a4-a6: epoch post-processing
 # --------------------------------------------------------------------------------------
 

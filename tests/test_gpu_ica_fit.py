@@ -108,3 +108,39 @@ def test_find_bads_eog_matches_oracle():
     assert len(want_idx) >= 1, "the synthetic blink component must be detectable"
     assert idx == want_idx
     assert np.abs(scores - want_scores).max() <= 2e-3
+
+
+def test_preprocess_recording_matches_oracle_flow():
+    """training/preprocess.py end to end on a synthetic continuous recording: filter -> notch -> ICA fit -> apply ->
+    trials / labels -> epochs -> baseline -> z-score, GPU stages vs the oracle's float64 restatement of each."""
+    rs = np.random.RandomState(8)
+    C, T, fs = 12, 90000, 500.0
+    x, _ = _mixture(C, T, seed=8)
+    ann, t = [], 4.0
+    while t < T / fs - 6.0:
+        ann.append((t, str(rs.choice([251, 252]))))
+        t += rs.choice([0.3, 0.45, 0.7, 1.2, 0.05])          # includes RTs under the 100 ms filter
+        ann.append((t, "253"))
+        t += rs.uniform(2.0, 5.0)
+    ann.append((T / fs - 0.2, "251")); ann.append((T / fs - 0.1, "253"))    # window leaves the recording: dropped
+    # a tight FastICA tolerance puts both runs on the fixed point (at the default 1e-4 the stopping iteration itself is
+    # sensitive to the fp32-vs-float64 difference of the filtered input)
+    got = lbm_amd.preprocess_recording(x, fs, ann, exclude=[1], ica_fit_params=dict(tol=1e-9))
+    # oracle flow
+    y = orc.filter_data(x, fs, 4.0, 30.0)
+    y = orc.notch_filter(y, fs, 60.0)
+    ref = orc.ica_fit(y, tol=1e-9)
+    keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")
+    y = orc.ica_apply(y, *(ref[k] for k in keys), exclude=[1])
+    events, labels, _, base = orc.vigilance_trials(ann, fs)
+    lo, hi = int(round(-0.5 * fs)), int(round(1.5 * fs))
+    ok = (events[:, 0] + lo >= 0) & (events[:, 0] + hi < T)
+    events, labels = events[ok], labels[ok]
+    ep = np.stack([y[:, s + lo:s + hi + 1] for s in events[:, 0]])
+    want = orc.zscore_epoch_channel(orc.baseline_correct(ep, orc.n_baseline_samples(-0.5, fs)))
+    assert got["labels"].tolist() == labels.tolist() and np.array_equal(got["events"], events)
+    assert got["alert_rt_baseline"] == base
+    assert abs(got["ica"]["n_iter"] - ref["n_iter"]) <= 2 and got["ica"]["exclude"] == [1]
+    out = got["epochs"].cpu().numpy()
+    assert out.shape == want.shape and len(labels) >= 10
+    assert np.abs(out - want).max() <= 5e-3, np.abs(out - want).max()       # z-scored units; ICA fit agrees to ~1e-3
