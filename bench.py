@@ -218,6 +218,27 @@ def main():
                             "tflops": round(model[name]["flops"] / (m * 1e-3) / 1e12, 3),
                             "gbs": round(model[name]["bytes"] / (m * 1e-3) / 1e9, 1)}
 
+    # non-default variants of the tokenizer tail, same chunk, outside the timed region (reported, never `value`)
+    variants = {}
+    if rank == 0 and args.shape == "S" and not args.fold_proj and args.vq == "fp32":
+        base_ms = sum(v["ms"] for v in stages.values())
+        for name, kw in (("vq_bf16x6", dict(vq_method="bf16x6")),
+                         ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True))):
+            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1, **kw)
+            vp = lbm_amd.EpochPipeline(vcfg, taps, A, b, weights, codebook, device=dev)
+            vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z is unused when folded)
+            vp.run(x[:chunk])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                vp.run(x[:chunk])
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            variants[name] = {"ms_per_chunk": round(ms, 3), "epochs_per_s": round(chunk / (ms * 1e-3), 1),
+                              "default_ms_per_chunk": round(base_ms, 3)}
+
     if rank == 0:
         dom = max(stages, key=lambda k: stages[k]["ms"])      # the dominant single kernel of a chunk
         traffic = None
@@ -254,6 +275,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "stages": stages,
+            "variants": variants,
         }
         print(json.dumps(line))
     if world > 1:

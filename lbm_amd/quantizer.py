@@ -34,14 +34,15 @@ def fold_projection(codebook, proj_weight, proj_bias=None):
     and the z tensor disappear.  Tokens differ from the unfolded path only at fp32 near-ties.
     Returns ``(codebook' [K, Cin], e_sqnorm' [K])`` as float32 tensors on the codebook's device.
     """
-    E = codebook.detach().to(torch.float64)
-    W = proj_weight.detach().to(torch.float64).reshape(proj_weight.shape[0], -1)        # [D, Cin] (ksize 1)
+    dev = codebook.device
+    E = codebook.detach().to("cpu", torch.float64)                                       # tiny: float64 on the host
+    W = proj_weight.detach().to("cpu", torch.float64).reshape(proj_weight.shape[0], -1)  # [D, Cin] (ksize 1)
     if W.shape[0] != E.shape[1]:
         raise ValueError(f"projection has {W.shape[0]} output channels, codebook dim is {E.shape[1]}")
     c = (E * E).sum(dim=1)
     if proj_bias is not None:
-        c = c - 2.0 * (E @ proj_bias.detach().to(torch.float64))
-    return (E @ W).to(torch.float32).contiguous(), c.to(torch.float32).contiguous()
+        c = c - 2.0 * (E @ proj_bias.detach().to("cpu", torch.float64))
+    return (E @ W).to(torch.float32).contiguous().to(dev), c.to(torch.float32).contiguous().to(dev)
 
 
 def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
