@@ -102,8 +102,9 @@ def pair_trials(times, codes, sfreq: float, deviation_codes=DEVIATION_CODES, res
     return {k: np.asarray(v, dtype=np.float64 if "time" in k or "rt" in k else np.int64) for k, v in out.items()}
 
 
-def vigilance_labels(local_rt_sec, rt_filter: float = RT_FILTER_THRESHOLD):
-    """RT filter, alert baseline and labels (training/preprocess.py:201-237).
+def vigilance_labels(local_rt_sec, rt_filter: float = RT_FILTER_THRESHOLD, percentile: float = 5.0):
+    """RT filter, alert baseline and labels (training/preprocess.py:201-237; multi-train/withpsd.py:184-194 uses the
+    10th percentile: ``percentile=10``).
 
     Returns ``(keep mask over the trials, labels of the kept trials, alert_rt_baseline)``: baseline = 5th percentile of
     the kept RTs (median when fewer than 5), alert < 1.5 * baseline, drowsy > 2.5 * baseline, else transition.
@@ -113,15 +114,17 @@ def vigilance_labels(local_rt_sec, rt_filter: float = RT_FILTER_THRESHOLD):
     kept = rt[keep]
     if kept.size == 0:
         return keep, np.asarray([], dtype="<U10"), float("nan")
-    base = float(np.median(kept)) if kept.size < 5 else float(np.percentile(kept, 5))
+    base = float(np.median(kept)) if kept.size < 5 else float(np.percentile(kept, percentile))
     lab = np.where(kept < 1.5 * base, "alert", np.where(kept > 2.5 * base, "drowsy", "transition"))
     return keep, lab.astype("<U10"), base
 
 
-def mne_events(trials: Dict[str, np.ndarray], keep: np.ndarray, labels: np.ndarray) -> np.ndarray:
-    """``[response_sample, 0, id]`` rows (training/preprocess.py:251-259)."""
+def mne_events(trials: Dict[str, np.ndarray], keep: np.ndarray, labels: np.ndarray, lock: str = "response") -> np.ndarray:
+    """``[sample, 0, id]`` rows: response-locked (training/preprocess.py:251-259) or, ``lock='deviation'``,
+    stimulus-locked (multi-train/withpsd.py:204)."""
     ids = np.asarray([VIGILANCE_EVENT_IDS[str(lab)] for lab in labels], dtype=np.int64)
-    return np.stack([trials["response_sample"][keep], np.zeros_like(ids), ids], axis=1) if ids.size else np.zeros((0, 3), dtype=np.int64)
+    col = trials["response_sample" if lock == "response" else "dev_sample"][keep]
+    return np.stack([col, np.zeros_like(ids), ids], axis=1) if ids.size else np.zeros((0, 3), dtype=np.int64)
 
 
 # ------------------------------------------------------------------------------------------------ driver
@@ -168,3 +171,57 @@ def preprocess_recording(data, sfreq: float, annotations, *, l_freq: float = FIL
     nb = n_baseline_samples(tmin, sfreq, 0.0 if BASELINE[1] is None else float(BASELINE[1]))
     _, std, _ = epoch_post(ep, n_baseline=nb, reject=None, standardize=True, eps=ZSCORE_EPSILON)        # :262 baseline, :279-287
     return dict(epochs=std, labels=labels, events=events, trials=trials, ica=state, alert_rt_baseline=base)
+
+
+def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: float = FILTER_LFREQ, h_freq: float = FILTER_HFREQ,
+                                 notch: Optional[float] = NOTCH_FREQ, ica: bool = True, n_components=ICA_N_COMPONENTS,
+                                 random_state=ICA_RANDOM_STATE, ica_fit_params=None, eog=None, exclude: Sequence[int] = (),
+                                 tmin: float = TMIN, tmax: float = TMAX, rt_filter: float = RT_FILTER_THRESHOLD,
+                                 reject: Optional[float] = 150e-6, psd_fmin: float = FILTER_LFREQ, psd_fmax: float = FILTER_HFREQ,
+                                 psd_window: str = "hann") -> dict:
+    """The per-file body of multi-train/withpsd.py (:96-283) on one continuous ``[C, T]`` recording: filter -> notch ->
+    ICA fit/apply -> trials (10th-percentile baseline, :192) -> stimulus-locked epochs (:204) with baseline and
+    peak-to-peak rejection (:213-219) -> Welch PSD per epoch (:236-250, n_fft = int(sfreq), half overlap, Hann) ->
+    ``Scaler(scalings='mean')`` over the kept epochs (:267-270).
+
+    Returns ``dict(time_epochs [E, C, Tw], psd_epochs [E, C, F], psd_freqs [F], labels [E], events, keep, ica)``;
+    ``save_withpsd_outputs`` writes them under the reference's file names.
+    """
+    from . import _lib
+    from .epochs import Scaler, epoch_post, make_epochs, n_baseline_samples
+    from .fastica import find_bads_eog, ica_fit
+    from .filter import filter_data, notch_filter
+    from .ica import ica_apply
+    from .psd import psd_array_welch
+
+    x = _lib.dev_f32(data)
+    if x.dim() != 2:
+        raise ValueError("preprocess_recording_withpsd: data must be [channels, samples]")
+    x = filter_data(x, sfreq, l_freq, h_freq)                                          # :118
+    if notch is not None and notch < sfreq / 2.0:
+        x = notch_filter(x, sfreq, notch)                                              # :119
+    state = None
+    if ica:
+        state = ica_fit(x, n_components=n_components, method=ICA_METHOD, random_state=random_state, fit_params=ica_fit_params)
+        bad = [int(i) for i in exclude]
+        if eog is not None:
+            idx, _ = find_bads_eog(state, x, eog, sfreq)                               # :136-139 (default threshold)
+            bad.extend(idx)
+        state["exclude"] = sorted(set(bad))
+        keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")
+        x = ica_apply(x.unsqueeze(0), exclude=state["exclude"], **{k: state[k] for k in keys})[0]       # :152
+    times, codes = extract_events([(t, str(d).strip()) for t, d in annotations])       # :161 strips the description
+    trials = pair_trials(times, codes, sfreq)
+    keep_rt, labels, base = vigilance_labels(trials["local_rt_sec"], rt_filter, percentile=10.0)
+    events = mne_events(trials, keep_rt, labels, lock="deviation")
+    ep, inside = make_epochs(x, events[:, 0], tmin, tmax, sfreq)
+    labels, events = labels[inside], events[inside]
+    nb = n_baseline_samples(tmin, sfreq, 0.0 if BASELINE[1] is None else float(BASELINE[1]))
+    base_ep, _, keep = epoch_post(ep, n_baseline=nb, reject=reject, standardize=False)
+    if keep is not None:
+        base_ep, labels, events = base_ep[keep], labels[keep.cpu().numpy()], events[keep.cpu().numpy()]
+    n_fft = int(sfreq * 1.0)                                                            # :231
+    psd, freqs = psd_array_welch(base_ep, sfreq, psd_fmin, psd_fmax, n_fft=n_fft, n_overlap=n_fft // 2, window=psd_window)
+    std = Scaler(scalings="mean").fit_transform(base_ep) if base_ep.shape[0] else base_ep
+    return dict(time_epochs=std, psd_epochs=psd, psd_freqs=freqs, labels=labels, events=events, keep=keep, ica=state,
+                alert_rt_baseline=base)

@@ -377,12 +377,14 @@ def find_bads_eog(ica: dict, data, eog, sfreq, threshold=3.0, l_freq=1.0, h_freq
 # 8(f)-4: annotations -> trials -> vigilance labels (training/preprocess.py:156-259), line-by-line semantics
 # --------------------------------------------------------------------------------------
 
-def vigilance_trials(annotations, sfreq, deviation_codes=(251, 252), response_code=253, rt_filter=0.1):
-    """Returns (events [E, 3] int, labels [E] str, rts [E], alert_rt_baseline) exactly as the script builds them."""
+def vigilance_trials(annotations, sfreq, deviation_codes=(251, 252), response_code=253, rt_filter=0.1, percentile=5,
+                     lock="response"):
+    """Returns (events [E, 3] int, labels [E] str, rts [E], alert_rt_baseline) exactly as the script builds them.
+    multi-train/withpsd.py:159-206 is the same logic with ``percentile=10`` and stimulus-locked events (``lock='deviation'``)."""
     ev = []
     for onset, desc in annotations:                                     # :157-165
         try:
-            code = int(float(desc))
+            code = int(float(str(desc).strip()))
         except (ValueError, TypeError):
             continue
         if code in deviation_codes or code == response_code:
@@ -396,13 +398,13 @@ def vigilance_trials(annotations, sfreq, deviation_codes=(251, 252), response_co
             if last is not None:
                 rt = t - last[0]
                 if rt >= 0:
-                    trials.append((int(round(t * sfreq)), rt))
+                    trials.append((int(round((t if lock == "response" else last[0]) * sfreq)), rt))
                 last = None
     trials = [tr for tr in trials if tr[1] >= rt_filter]                 # :204
     rts = np.asarray([tr[1] for tr in trials], dtype=np.float64)
     if rts.size == 0:
         return np.zeros((0, 3), dtype=np.int64), np.asarray([], dtype="<U10"), rts, float("nan")
-    base = float(np.median(rts)) if rts.size < 5 else float(np.percentile(rts, 5))      # :216-225
+    base = float(np.median(rts)) if rts.size < 5 else float(np.percentile(rts, percentile))      # :216-225
     labels = []
     for rt in rts:                                                       # :233-236
         labels.append("alert" if rt < 1.5 * base else ("drowsy" if rt > 2.5 * base else "transition"))

@@ -144,3 +144,35 @@ def test_preprocess_recording_matches_oracle_flow():
     out = got["epochs"].cpu().numpy()
     assert out.shape == want.shape and len(labels) >= 10
     assert np.abs(out - want).max() <= 5e-3, np.abs(out - want).max()       # z-scored units; ICA fit agrees to ~1e-3
+
+
+def test_preprocess_recording_withpsd_matches_oracle_flow():
+    """multi-train/withpsd.py per-file body: 10th-percentile labels, stimulus-locked epochs with rejection, Welch PSD
+    per epoch, Scaler over the kept epochs."""
+    rs = np.random.RandomState(9)
+    C, T, fs = 8, 70000, 500.0
+    x, _ = _mixture(C, T, seed=9, scale=4e-7)
+    ann, t = [], 4.0
+    while t < T / fs - 6.0:
+        ann.append((t, f" {rs.choice([251, 252])} "))           # the script strips the description
+        ann.append((t + rs.choice([0.3, 0.45, 0.7, 1.2, 0.05]), "253"))
+        t += rs.uniform(2.5, 5.0)
+    x[3, 30000:30040] += 4e-4                                     # an artefact inside one epoch window: rejected
+    got = lbm_amd.preprocess_recording_withpsd(x, fs, ann, ica=False)
+    y = orc.notch_filter(orc.filter_data(x, fs, 4.0, 30.0), fs, 60.0)
+    events, labels, _, base = orc.vigilance_trials(ann, fs, percentile=10, lock="deviation")
+    lo, hi = int(round(-0.5 * fs)), int(round(1.5 * fs))
+    ok = (events[:, 0] + lo >= 0) & (events[:, 0] + hi < T)
+    events, labels = events[ok], labels[ok]
+    ep = orc.baseline_correct(np.stack([y[:, s + lo:s + hi + 1] for s in events[:, 0]]), orc.n_baseline_samples(-0.5, fs))
+    keep = orc.ptp_keep_mask(ep, 150e-6)
+    assert 0 < keep.sum() < len(keep)
+    ep, events, labels = ep[keep], events[keep], labels[keep]
+    assert got["labels"].tolist() == labels.tolist() and np.array_equal(got["events"], events)
+    assert got["alert_rt_baseline"] == base
+    psd, freqs = orc.welch_psd(ep, fs, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann")
+    np.testing.assert_array_equal(got["psd_freqs"], freqs)
+    gp = got["psd_epochs"].cpu().numpy()
+    assert np.abs(gp - psd).max() <= 2e-4 * psd.max()
+    want = orc.scaler_mean(ep)
+    assert np.abs(got["time_epochs"].cpu().numpy() - want).max() <= 2e-3

@@ -76,3 +76,14 @@ def test_read_raw_eeglab_round_trip(tmp_path, external_fdt):
     np.testing.assert_allclose(raw["data"], data_uv.astype(np.float64) * 1e-6, rtol=0, atol=0)
     assert raw["annotations"] == [(100.0 / fs, "251"), (250.0 / fs, "253"), (399.0 / fs, "boundary")]
     assert lbm_amd.pick_eeg_channels(raw["ch_names"]) == [0, 1, 2, 4]
+
+
+def test_withpsd_variant_options():
+    rs = np.random.RandomState(4)
+    ann = _annotations(rs, 200)
+    want_ev, want_lab, want_rt, want_base = orc.vigilance_trials(ann, 500.0, percentile=10, lock="deviation")
+    times, codes = lbm_amd.extract_events(ann)
+    trials = lbm_amd.pair_trials(times, codes, 500.0)
+    keep, labels, base = lbm_amd.vigilance_labels(trials["local_rt_sec"], percentile=10.0)
+    assert np.array_equal(lbm_amd.mne_events(trials, keep, labels, lock="deviation"), want_ev)
+    assert labels.tolist() == want_lab.tolist() and base == want_base
