@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--emit-cleaned", action="store_true",
+                    help="also write the baseline-corrected epochs (+180 000 B/epoch; not among SURVEY.md 8(d)'s compulsory outputs)")
     ap.add_argument("--vq", choices=["fp32", "bf16x6"], default="fp32",
                     help="codebook argmin kernel: fp32 MFMA (default) or fp32 products from three bf16 pieces on the bf16 MFMA")
     ap.add_argument("--fold-proj", action="store_true",
@@ -136,7 +138,7 @@ def main():
         weights = synth_encoder(C)
     codebook = weights["vq_layer.embedding.weight"] if (K == 512 and args.shape == "S") else synth_codebook(K, D)
     cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1,
-                                 fold_projection=args.fold_proj, vq_method=args.vq)
+                                 fold_projection=args.fold_proj, vq_method=args.vq, emit_cleaned=args.emit_cleaned)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -212,6 +214,8 @@ def main():
         pipe.stage_events = None
         fft_n = 2048 if args.shape == "S" else 3 * 4096
         model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n)
+        if not args.emit_cleaned:
+            model["post"]["bytes"] = 2.0 * C * T * 4 * chunk      # one read, one write (standardized)
         for name, ms in acc.items():
             m = float(np.mean(ms))
             stages[name] = {"ms": round(m, 4), "bound": model[name]["bound"],
@@ -224,7 +228,7 @@ def main():
         base_ms = sum(v["ms"] for v in stages.values())
         for name, kw in (("vq_bf16x6", dict(vq_method="bf16x6")),
                          ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True))):
-            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1, **kw)
+            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1, emit_cleaned=args.emit_cleaned, **kw)
             vp = lbm_amd.EpochPipeline(vcfg, taps, A, b, weights, codebook, device=dev)
             vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z is unused when folded)
             vp.run(x[:chunk])
@@ -270,7 +274,8 @@ def main():
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq,
+                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "emit_cleaned": bool(args.emit_cleaned),
+                       "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
                        "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -36,6 +36,10 @@ class PipelineConfig:
     do_filter: bool = True
     do_ica: bool = True
     fir_method: str = "fft"            # 'fft' (fast convolution) or 'direct' (LDS direct form)
+    emit_cleaned: bool = True          # write the baseline-corrected epochs (output "cleaned").  No other output depends
+                                       # on the baseline offset: Welch removes each segment's mean, peak-to-peak and the
+                                       # z-score are offset-invariant -- so False saves one 180 000 B/epoch write
+                                       # (the 186 264 B/epoch compulsory figure excludes cleaned epochs)
     vq_method: str = "fp32"            # 'fp32': exact fmaf chain on the fp32 MFMA; 'bf16x6': fp32 products rebuilt from three
                                        # bf16 pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
     fold_projection: bool = False      # tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook
@@ -147,8 +151,9 @@ class EpochPipeline:
             _lib.check(lib.lbm_affine_ch_f32(p(cur), p(B["clean"]), E, C, C, T, p(self.A), p(self.b), st), "affine")
             cur = B["clean"]
             t0 = mark("affine", t0)
-        base = B["clean"]
-        _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base), p(B["std"]) if c.do_tokenize else None, p(B["keep"]), E, C, T,
+        base = B["clean"] if c.emit_cleaned else cur      # the PSD is the same with or without the baseline offset
+        _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base) if c.emit_cleaned else None, p(B["std"]) if c.do_tokenize else None,
+                                          p(B["keep"]), E, C, T,
                                           c.n_baseline, float(c.reject),
                                           _lib.STD_EPOCH_CHANNEL if c.do_tokenize else _lib.STD_NONE, c.zscore_eps, st), "post")
         t0 = mark("post", t0)
@@ -157,7 +162,9 @@ class EpochPipeline:
         t0 = mark("welch", t0)
         _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
         t0 = mark("bandpower", t0)
-        out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"], "cleaned": base}
+        out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"]}
+        if c.emit_cleaned:
+            out["cleaned"] = base
         if c.do_tokenize:
             e = self.enc
             conv = lambda xi, ldx, yo, ldy, i, cin, lin, cout, ks, s_, pd, relu: _lib.check(  # noqa: E731

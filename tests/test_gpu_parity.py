@@ -539,6 +539,23 @@ def test_pipeline_folded_projection_tokens(shipped, vq_golden, codebook, vq_meth
         assert orc.vq_near_tie_ok(zg, cb, tk.reshape(-1), vq_golden["tokens_S"].reshape(-1)).all()
 
 
+def test_pipeline_without_cleaned_output(shipped):
+    """emit_cleaned=False: no "cleaned" tensor; tokens / keep / standardized identical, PSD equal to fp32 rounding
+    (Welch removes each segment's mean, so the baseline offset never reaches it)."""
+    pipe, taps, A, b = _make_pipeline(shipped, T=1500)
+    pipe2 = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(emit_cleaned=False), taps, A, b, shipped, shipped["vq_layer.embedding.weight"])
+    x = (synth_epochs(40, 30, 1500, seed=12) * 2.0)
+    x[3, 5, 100] += 1e-2
+    x = x.to(DEV)
+    ref = {k: v.clone() for k, v in pipe.run(x).items()}
+    out = pipe2.run(x)
+    assert "cleaned" not in out
+    for k in ("tokens", "keep", "standardized", "hist"):
+        assert torch.equal(out[k], ref[k]), k
+    assert _psd_err(out["psd"].cpu().numpy(), ref["psd"].cpu().numpy().astype(np.float64)) <= 4.0
+    np.testing.assert_allclose(out["bandpower"].cpu().numpy(), ref["bandpower"].cpu().numpy(), rtol=2e-6)
+
+
 def test_pipeline_bf16x6_quantizer_tokens(shipped):
     """The pipeline with the bf16-piece argmin kernel: tokens of the fp32-MFMA path except documented near-ties."""
     pipe, taps, A, b = _make_pipeline(shipped, T=1500)
