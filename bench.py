@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="non-default: every chunk arrives from pinned host memory (PCIe-inclusive rate; H2D copies of chunk i+1 "
+                         "on a copy stream overlap the kernels of chunk i)")
     ap.add_argument("--emit-cleaned", action="store_true",
                     help="also write the baseline-corrected epochs (+180 000 B/epoch; not among SURVEY.md 8(d)'s compulsory outputs)")
     ap.add_argument("--vq", choices=["fp32", "bf16x6"], default="fp32",
@@ -155,7 +158,42 @@ def main():
     synth_epochs(R, C, T, sfreq=fs, seed=lbm_amd.synth.SEED + rank, device=dev, chunk=2048, out=x)
     torch.cuda.synchronize()
 
+    host_ring = dev_ring = copy_stream = None
+    if args.from_host:
+        copy_stream = torch.cuda.Stream()
+        host_ring = [x[:chunk].cpu().pin_memory() for _ in range(2)]
+        dev_ring = [torch.empty((chunk, C, T), dtype=torch.float32, device=dev) for _ in range(2)]
+
+    def step_from_host():
+        pipe.reset_hist()
+        nchunks = (E + chunk - 1) // chunk
+        ready = [torch.cuda.Event() for _ in range(2)]
+        freed = [torch.cuda.Event() for _ in range(2)]
+        with torch.cuda.stream(copy_stream):
+            dev_ring[0].copy_(host_ring[0], non_blocking=True)
+            ready[0].record(copy_stream)
+        for i in range(nchunks):
+            cur = i & 1
+            if i + 1 < nchunks:
+                with torch.cuda.stream(copy_stream):
+                    if i >= 1:
+                        copy_stream.wait_event(freed[cur ^ 1])          # the kernels of chunk i-1 have consumed that buffer
+                    dev_ring[cur ^ 1].copy_(host_ring[cur ^ 1], non_blocking=True)
+                    ready[cur ^ 1].record(copy_stream)
+            torch.cuda.current_stream().wait_event(ready[cur])
+            lo = i * chunk
+            n = min(chunk, E - lo)
+            out = pipe.run(dev_ring[cur][:n])
+            freed[cur].record()
+            tokens[lo:lo + n].copy_(out["tokens"])
+            psd[lo:lo + n].copy_(out["psd"])
+            bp[lo:lo + n].copy_(out["bandpower"])
+            keep[lo:lo + n].copy_(out["keep"])
+        return pipe._buf["hist"]
+
     def step():
+        if args.from_host:
+            return step_from_host()
         pipe.reset_hist()
         for lo in range(0, E, chunk):
             n = min(chunk, E - lo)
@@ -268,13 +306,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" + (" (chunks streamed from pinned host memory)" if args.from_host else ""),
             "config": {"workload": "%s: full pipeline (%d-tap FIR + ICA affine + baseline/reject/z-score + Welch PSD "
                                    "+ band power + VQ-VAE encoder + K=%d codebook argmin), %dch x %gHz x %gs fp32 epochs, "
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "emit_cleaned": bool(args.emit_cleaned),
+                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
                        "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
             "roofline": roof,
