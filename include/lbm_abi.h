@@ -101,6 +101,19 @@ int lbm_ica_stats_f32(const float* z, int64_t ldz, int64_t T, int32_t n, const f
 int lbm_epochs_gather_f32(const float* raw, int64_t ldr, const int64_t* starts, float* out, int64_t E, int32_t C,
                           int32_t Tw, int64_t Trec, lbm_stream_t stream);
 
+/* ---- 8(f)-4: FFT resampling of a continuous recording ----------------------------------------------------
+ * Replaces raw.resample(250) at preprocessing_unsupervised.py:37 (mne.filter.resample(x, up, down, npad='auto',
+ * window='boxcar', pad='reflect_limited')): each row is padded to the next power of two N by odd reflection,
+ * transformed, cut (or extended) to round(ratio * N) bins with MNE's Nyquist-bin rule, transformed back and
+ * trimmed to lbm_resample_length(T, up, down) = round(T * up / down) samples (round-half-even).
+ * x: [rows, T] with pitch ldx; y: [rows, length] with pitch ldy; workspace: lbm_resample_workspace_bytes bytes.
+ * Supported ratios: up/down = 2^s (the resampled padded length must stay a power of two); others return
+ * LBM_EUNSUPPORTED (workspace_bytes / length return 0).  rows <= 65535 per call. */
+int64_t lbm_resample_length(int64_t T, int32_t up, int32_t down);
+size_t lbm_resample_workspace_bytes(int64_t rows, int64_t T, int32_t up, int32_t down);
+int lbm_resample_fft_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t T, int32_t up,
+                         int32_t down, void* workspace, lbm_stream_t stream);
+
 /* ---- a4 / a5 / a6: epoch post-processing ----------------------------------------------------------
  * Replaces mne.Epochs(..., baseline=(None, 0)) baseline correction (training/preprocess.py:262-271),
  * reject=dict(eeg=150e-6)+drop_bad (multi-train/withpsd.py:44-46,213-219) and the per-epoch

@@ -7,7 +7,7 @@ hand-written HIP kernels behind the C ABI of include/lbm_abi.h (lbm_amd/liblbm_h
 """
 from .constants import *  # noqa: F401,F403
 from . import _lib  # noqa: F401
-from .filter import create_filter, filter_data, notch_filter, fir_apply  # noqa: F401
+from .filter import create_filter, filter_data, notch_filter, fir_apply, resample  # noqa: F401
 from .ica import ica_apply, ica_get_sources, ica_projection, affine_channels, average_reference_matrix  # noqa: F401
 from .fastica import ica_fit, find_bads_eog, fastica_parallel, ica_stats, channel_moments  # noqa: F401
 from .epochs import (epoch_post, standardize_epochs, Scaler, n_baseline_samples, make_epochs,  # noqa: F401

@@ -35,6 +35,9 @@ SIGNATURES = {
     "lbm_ica_stats_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "lbm_ica_stats_f32": (C.c_int, [_p, _i64, _i64, _i32, _p, _i32, _f32, _p, _p, _p, _p]),
     "lbm_epochs_gather_f32": (C.c_int, [_p, _i64, _p, _p, _i64, _i32, _i32, _i64, _p]),
+    "lbm_resample_length": (C.c_int64, [_i64, _i32, _i32]),
+    "lbm_resample_workspace_bytes": (C.c_size_t, [_i64, _i64, _i32, _i32]),
+    "lbm_resample_fft_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _p]),
     "lbm_epoch_post_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _p]),
     "lbm_channel_moments_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_channel_scale_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p]),

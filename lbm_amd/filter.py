@@ -170,3 +170,31 @@ def notch_filter(data, sfreq, freqs, *, notch_widths=None, trans_bandwidth=1.0, 
     for taps in notch_taps(sfreq, freqs, notch_widths, trans_bandwidth, fir_window):
         y = fir_apply(y, taps, pad)
     return y.cpu().numpy().astype(np.float64) if was_numpy else y
+
+
+def resample(data, up: int = 1, down: int = 1):
+    """``mne.filter.resample(data, up, down, npad='auto', window='boxcar', pad='reflect_limited')`` along the last axis
+    (``raw.resample(250)`` at preprocessing_unsupervised.py:37 is ``resample(data, 250, 500)`` after reduction).
+    Ratios 2^s only (see ``lbm_resample_fft_f32``)."""
+    from math import gcd
+    up, down = int(up), int(down)
+    g = gcd(up, down)
+    up, down = up // g, down // g
+    was_numpy = not isinstance(data, torch.Tensor)
+    x = _lib.dev_f32(data)
+    T = x.shape[-1]
+    rows = x.numel() // max(T, 1)
+    lib = _lib.load()
+    n_out = lib.lbm_resample_length(T, up, down)
+    nbytes = lib.lbm_resample_workspace_bytes(min(rows, 64), T, up, down) if rows else 0
+    if T and (n_out == 0 or nbytes == 0):
+        raise NotImplementedError(f"resample: ratio {up}/{down} of {T} samples is not supported (ratios 2^s only)")
+    x2 = x.reshape(rows, T)
+    y = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    for lo in range(0, rows, 64):                                   # 64 rows per call bound the workspace (1 GiB at 2^21 points)
+        n = min(64, rows - lo)
+        _lib.check(lib.lbm_resample_fft_f32(_lib.ptr(x2[lo:]), T, _lib.ptr(y[lo:]), n_out, n, T, up, down, _lib.ptr(ws),
+                                            _lib.stream_ptr()), "lbm_resample_fft_f32")
+    y = y.reshape(*x.shape[:-1], n_out)
+    return y.cpu().numpy().astype(np.float64) if was_numpy else y

@@ -200,6 +200,48 @@ def notch_filter(x, sfreq, freqs, fft: bool = False, **kw):
     return y
 
 
+def resample(x, up=1.0, down=1.0):
+    """``mne.filter.resample(x, up, down, npad='auto', window='boxcar', pad='reflect_limited')`` along the last axis
+    (``raw.resample(250)``, preprocessing_unsupervised.py:37), restated from MNE 1.5 (parity unpinned)."""
+    x = np.asarray(x, dtype=np.float64)
+    T = x.shape[-1]
+    ratio = float(up) / float(down)
+    final_len = int(round(ratio * T))
+    min_add = min(T // 8, 100) * 2
+    npad = 2 ** int(np.ceil(np.log2(T + 2 * min_add))) - T
+    npads = np.array([npad // 2, npad - npad // 2])
+    orig_len = T + npad
+    new_len = max(int(round(ratio * orig_len)), 1)
+    rem0 = int(round(ratio * npads[0]))
+    rem1 = new_len - final_len - rem0
+    shorter = new_len < orig_len
+    use_len = new_len if shorter else orig_len
+    W = np.ones(use_len) * (float(new_len) / float(orig_len))     # boxcar window, ifftshift is the identity on ones
+    W = W[: use_len // 2 + 1]
+    out = np.empty(x.shape[:-1] + (final_len,))
+    for idx in np.ndindex(*x.shape[:-1]):
+        row = x[idx]
+        pad = np.concatenate([_reflect_limited_side(row, npads[0], left=True), row, _reflect_limited_side(row, npads[1], left=False)])
+        xf = np.fft.rfft(pad)[: use_len // 2 + 1].copy()
+        if use_len % 2 == 0:
+            xf[use_len // 2] *= 2 if shorter else 0.5
+        xf *= W
+        y = np.fft.irfft(xf, new_len)
+        out[idx] = y[rem0:new_len - rem1]
+    return out
+
+
+def _reflect_limited_side(x, n_pad, left):
+    """One side of MNE ``_smart_pad(..., 'reflect_limited')``: odd reflection while samples last, zeros beyond."""
+    n = len(x)
+    k = min(n_pad, n - 1)
+    if left:
+        ref = 2 * x[0] - x[k:0:-1]
+        return np.concatenate([np.zeros(n_pad - k), ref])
+    ref = 2 * x[-1] - x[-2:-k - 2:-1]
+    return np.concatenate([ref, np.zeros(n_pad - k)])
+
+
 # --------------------------------------------------------------------------------------
 # a3: ICA apply / sources (MNE ``ICA.apply`` / ``get_sources``; SURVEY.md App. A2)
 # reference call sites: training/preprocess.py:144 ; multi-train/withpsd.py:152 ;

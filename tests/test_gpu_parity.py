@@ -619,3 +619,30 @@ def test_pipeline_full_size_properties(shipped):
     assert torch.equal(torch.cat([oa["tokens"], ob["tokens"]]), o1["tokens"][:1777])   # epochs are independent
     assert torch.equal(torch.cat([oa["psd"], ob["psd"]]), o1["psd"][:1777])
     assert bool(torch.isfinite(o1["psd"]).all()) and bool((o1["psd"] > 0).all())
+
+
+# ------------------------------------------------------------------------------------------------ 8(f)-4 resample
+@pytest.mark.parametrize("T,up,down,rows", [(5000, 1, 2, 3), (1001, 1, 2, 2), (30000, 250, 1000, 2), (65539, 250, 500, 1), (3000, 2, 1, 2),
+                                            (70, 1, 2, 1), (300000, 1, 2, 70)])
+def test_resample_matches_oracle(T, up, down, rows):
+    """raw.resample (preprocessing_unsupervised.py:37): FFT resampling with MNE's auto padding, vs the float64 oracle."""
+    rs = np.random.RandomState(T)
+    t = np.arange(T) / 500.0
+    x = (np.sin(2 * np.pi * 7 * t)[None] * rs.uniform(0.5, 2, (rows, 1)) + 0.2 * rs.randn(rows, T).cumsum(axis=1) / 20 + 0.1 * rs.randn(rows, T))
+    x = (x * 1e-5).astype(np.float32)
+    got = lbm_amd.resample(torch.from_numpy(x).to(DEV), up, down).cpu().numpy()
+    sub = slice(0, min(rows, 4))                                    # the oracle loops over rows in Python
+    want = orc.resample(x[sub].astype(np.float64), up, down)
+    assert got.shape == (rows, want.shape[1])
+    assert np.abs(got[sub] - want).max() <= 2e-5 * np.abs(x).max()
+    if rows > 4:                                                    # every launch group computes the same function
+        want_last = orc.resample(x[-1:].astype(np.float64), up, down)
+        assert np.abs(got[-1:] - want_last).max() <= 2e-5 * np.abs(x).max()
+
+
+def test_resample_unsupported_ratio_and_empty():
+    with pytest.raises(NotImplementedError):
+        lbm_amd.resample(torch.zeros(2, 1000, device=DEV), 250, 512)
+    lib = _lib.load()
+    assert lib.lbm_resample_length(1001, 1, 2) == 500 and lib.lbm_resample_length(1003, 1, 2) == 502      # round-half-even
+    assert lib.lbm_resample_fft_f32(None, 0, None, 0, 0, 100, 1, 2, None, None) == 0

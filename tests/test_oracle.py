@@ -181,3 +181,19 @@ def test_welch_manual_restatement():
     np.testing.assert_allclose(pm, np.median(pn, -1) / (1 + 1 / 3 - 1 / 2 + 1 / 5 - 1 / 4), rtol=1e-12)
     with pytest.raises(ValueError):
         orc.welch_psd(rs.randn(100), 500.0, n_fft=500)
+
+
+def test_resample_oracle_band_limited_signal_and_lengths():
+    """The restated MNE resampler: a band-limited signal decimates to its own samples away from the edges, lengths
+    follow round-half-even, and the interior agrees with scipy.signal.resample on the same padded row."""
+    import numpy as np
+    from oracle import eeg_oracle as orc
+    t = np.arange(8000) / 500.0
+    x = np.sin(2 * np.pi * 7.3 * t) + 0.5 * np.cos(2 * np.pi * 31.0 * t + 0.4)
+    y = orc.resample(x[None], 250, 500)[0]
+    assert y.shape == (4000,)
+    assert np.abs(y[200:-200] - x[::2][200:-200]).max() < 2e-3
+    assert orc.resample(np.zeros((1, 1001)), 1, 2).shape == (1, 500)
+    assert orc.resample(np.zeros((1, 1003)), 1, 2).shape == (1, 502)
+    up = orc.resample(x[None, :1000], 2, 1)[0]
+    assert up.shape == (2000,) and np.abs(up[::2][50:-50] - x[:1000][50:-50]).max() < 2e-3
