@@ -16,5 +16,6 @@ from .psd import psd_array_welch, band_powers, classify_eeg_state, classify_eeg_
 from .quantizer import (VectorQuantizerEMA, VQVAE, encode_data_for_transformer, vq_argmin, vq_split_tables, fold_projection, conv1d,  # noqa: F401
                         encoder_forward, rownorm2, vq_gather_loss, perplexity_from_hist, vq_ema_sums, vq_ema_apply)
 from .recording import (read_raw_eeglab, pick_eeg_channels, extract_events, pair_trials, vigilance_labels,  # noqa: F401
-                        mne_events, preprocess_recording, preprocess_recording_withpsd)
+                        mne_events, preprocess_recording, preprocess_recording_withpsd,
+                        process_unsupervised_recording)
 from .pipeline import EpochPipeline, PipelineConfig, shard_range, gather_epoch_outputs, allreduce_hist  # noqa: F401

@@ -225,3 +225,43 @@ def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: flo
     std = Scaler(scalings="mean").fit_transform(base_ep) if base_ep.shape[0] else base_ep
     return dict(time_epochs=std, psd_epochs=psd, psd_freqs=freqs, labels=labels, events=events, keep=keep, ica=state,
                 alert_rt_baseline=base)
+
+
+def process_unsupervised_recording(data, sfreq: float, *, new_sfreq: float = 250.0, l_freq: float = 4.0, h_freq: float = 30.0,
+                                   n_components=20, random_state=42, ica_fit_params=None, n_fft: int = 512) -> dict:
+    """The per-file body of preprocessing_unsupervised.py:34-61 on one continuous ``[C, T]`` recording:
+    average reference (:35) -> 4-30 Hz FIR (:36) -> resample to 250 Hz (:37) -> ICA(n_components=20, random_state=42)
+    fit + apply with nothing excluded (:39-41) -> Welch PSD of the whole recording (``raw.compute_psd(fmin=4, fmax=30,
+    n_fft=512)``: Hamming, no overlap, :43) -> theta / alpha / beta dB means and their ratios (:45-61).
+
+    Returns ``dict(theta, alpha, beta, beta_theta, alpha_beta, theta_beta, psds [C, F], freqs [F], ica)``; the label of
+    the file is ``classify_eeg_state(theta, alpha, beta, median of theta_beta over the data set)`` (:66-84).
+    """
+    import torch
+    from . import _lib
+    from .fastica import ica_fit
+    from .filter import filter_data, resample
+    from .ica import affine_channels, average_reference_matrix, ica_apply
+    from .psd import band_powers, psd_array_welch
+
+    x = _lib.dev_f32(data)
+    if x.dim() != 2:
+        raise ValueError("process_unsupervised_recording: data must be [channels, samples]")
+    C = x.shape[0]
+    x = affine_channels(x, average_reference_matrix(C))                                # :35
+    x = filter_data(x, sfreq, l_freq, h_freq)                                          # :36
+    if float(new_sfreq) != float(sfreq):
+        x = resample(x, int(round(new_sfreq)), int(round(sfreq)))                      # :37
+    state = ica_fit(x, n_components=n_components, random_state=random_state, fit_params=ica_fit_params)   # :39-40
+    keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")
+    x = ica_apply(x.unsqueeze(0), exclude=[], **{k: state[k] for k in keys})[0]        # :41
+    # Welch with no overlap = mean of the per-segment periodograms: segments as rows, averaged in float64
+    nseg = x.shape[1] // n_fft
+    if nseg < 1:
+        raise ValueError("process_unsupervised_recording: recording shorter than n_fft")
+    seg = x[:, : nseg * n_fft].reshape(C * nseg, n_fft)
+    p, freqs = psd_array_welch(seg, new_sfreq, l_freq, h_freq, n_fft=n_fft, n_overlap=0, window="hamming")
+    psds = p.reshape(C, nseg, -1).to(torch.float64).mean(dim=1).to(torch.float32)      # [C, F]
+    bp = band_powers(psds.unsqueeze(0), freqs)[0].cpu().numpy().astype(np.float64)     # :45-61
+    return dict(theta=bp[0], alpha=bp[1], beta=bp[2], beta_theta=bp[3], alpha_beta=bp[4], theta_beta=bp[5], psds=psds,
+                freqs=np.asarray(freqs), ica=state)

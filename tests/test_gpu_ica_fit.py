@@ -176,3 +176,23 @@ def test_preprocess_recording_withpsd_matches_oracle_flow():
     assert np.abs(gp - psd).max() <= 2e-4 * psd.max()
     want = orc.scaler_mean(ep)
     assert np.abs(got["time_epochs"].cpu().numpy() - want).max() <= 2e-3
+
+
+def test_process_unsupervised_recording_matches_oracle_flow():
+    """preprocessing_unsupervised.py:34-61 on a synthetic recording: average reference, band-pass, resample to 250 Hz,
+    ICA(20, random_state=42) fit/apply, Welch PSD of the recording (n_fft 512, Hamming, no overlap), band powers."""
+    C, T, fs = 24, 80000, 500.0
+    x, _ = _mixture(C, T, seed=14)
+    got = lbm_amd.process_unsupervised_recording(x, fs, ica_fit_params=dict(tol=1e-9))
+    y = orc.average_reference_matrix(C) @ x
+    y = orc.resample(orc.filter_data(y, fs, 4.0, 30.0), 250, 500)
+    ref = orc.ica_fit(y, n_components=20, random_state=42, tol=1e-9)
+    keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")
+    y = orc.ica_apply(y, *(ref[k] for k in keys), exclude=[])
+    psd, freqs = orc.welch_psd(y, 250.0, 4.0, 30.0, n_fft=512, n_overlap=0, window="hamming")
+    assert len(freqs) == 53 and np.array_equal(got["freqs"], freqs)                  # the grid of the shipped X_psd_multi.npy
+    gp = got["psds"].cpu().numpy()
+    assert np.abs(gp - psd).max() <= 1e-3 * psd.max()
+    th, al, be, bt, ab, tb = orc.band_powers(psd, freqs)
+    for k, w in (("theta", th), ("alpha", al), ("beta", be), ("beta_theta", bt), ("alpha_beta", ab), ("theta_beta", tb)):
+        assert abs(got[k] - w) <= 2e-4 * abs(w), (k, got[k], w)
