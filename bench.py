@@ -95,6 +95,8 @@ def main():
                     help="also write the baseline-corrected epochs (+180 000 B/epoch; not among SURVEY.md 8(d)'s compulsory outputs)")
     ap.add_argument("--vq", choices=["fp32", "bf16x6"], default="fp32",
                     help="codebook argmin kernel: fp32 MFMA (default) or fp32 products from three bf16 pieces on the bf16 MFMA")
+    ap.add_argument("--conv", choices=["fp32", "bf16x6"], default="fp32",
+                    help="256-channel encoder layers: fp32 MFMA kernels (default) or the three-bf16-piece implicit GEMM")
     ap.add_argument("--fold-proj", action="store_true",
                     help="non-default variant: tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook "
                          "(PipelineConfig.fold_projection; no z tensor; equal tokens except fp32 near-ties)")
@@ -141,7 +143,8 @@ def main():
         weights = synth_encoder(C)
     codebook = weights["vq_layer.embedding.weight"] if (K == 512 and args.shape == "S") else synth_codebook(K, D)
     cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1,
-                                 fold_projection=args.fold_proj, vq_method=args.vq, emit_cleaned=args.emit_cleaned)
+                                 fold_projection=args.fold_proj, vq_method=args.vq, conv_method=args.conv,
+                                 emit_cleaned=args.emit_cleaned)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -262,10 +265,12 @@ def main():
 
     # non-default variants of the tokenizer tail, same chunk, outside the timed region (reported, never `value`)
     variants = {}
-    if rank == 0 and args.shape == "S" and not args.fold_proj and args.vq == "fp32":
+    if rank == 0 and args.shape == "S" and not args.fold_proj and args.vq == "fp32" and args.conv == "fp32":
         base_ms = sum(v["ms"] for v in stages.values())
         for name, kw in (("vq_bf16x6", dict(vq_method="bf16x6")),
-                         ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True))):
+                         ("vq_bf16x6+conv_bf16x6", dict(vq_method="bf16x6", conv_method="bf16x6")),
+                         ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True)),
+                         ("vq_bf16x6+conv_bf16x6+fold_projection", dict(vq_method="bf16x6", conv_method="bf16x6", fold_projection=True))):
             vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1, emit_cleaned=args.emit_cleaned, **kw)
             vp = lbm_amd.EpochPipeline(vcfg, taps, A, b, weights, codebook, device=dev)
             vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z is unused when folded)
@@ -312,7 +317,7 @@ def main():
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
                        "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
             "roofline": roof,

@@ -194,6 +194,18 @@ int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* w, const fl
                            int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride,
                            int32_t pad, int32_t relu, lbm_stream_t stream);
 
+/* The same layer on the bf16 matrix cores with fp32-grade products (three bf16 pieces per operand, six piece products,
+ * fp32 accumulate; see lbm_vq_argmin_bf16x6_f32 for the arithmetic and its measured accuracy): results within fp32
+ * rounding of lbm_conv1d_pitched_f32, not bit-identical to it.  The weights are passed pre-split:
+ * lbm_conv1d_split_tables_bytes(Cin, Cout, ksize) sizes a caller-owned, 16-byte aligned device table that
+ * lbm_conv1d_split_tables_init fills from the fp32 weights [Cout, Cin, ksize] (0 bytes = unsupported shape).
+ * Output channels are processed 256 at a time (Cout is padded up: meant for the wide layers).  Cin * ldx < 2^31. */
+size_t lbm_conv1d_split_tables_bytes(int32_t Cin, int32_t Cout, int32_t ksize);
+int lbm_conv1d_split_tables_init(void* tables, const float* w, int32_t Cin, int32_t Cout, int32_t ksize, lbm_stream_t stream);
+int lbm_conv1d_bf16x6_f32(const float* x, int64_t ldx, const void* tables, const float* bias, float* y, int64_t ldy, int64_t B,
+                          int32_t Cin, int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
+                          lbm_stream_t stream);
+
 /* ---- a12 / a13: codebook distance + argmin ----------------------------------------------------------
  * Replaces VectorQuantizerEMA.get_code_indices, training/model.py:152-158 (same math in forward :90-95):
  * d[n,k] = (sum(x_n^2) + sum(e_k^2)) - 2 * (x_n . e_k) in fp32, idx[n] = first k attaining the minimum.

@@ -17,36 +17,9 @@
 // splits its 128 x 16 slice of x on the fly into an LDS image [piece][row][16 bf16] (32-byte rows, 16-byte
 // halves swapped on odd row octets so the ds_read_b128 operand reads are conflict-free), double buffered, one
 // barrier per stage; 48 MFMAs per wave per stage.
-#include "common.h"
+#include "bf16x6.h"
 
 namespace {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kThreads = 256;
-constexpr int kRows = 128;        // input rows per workgroup
-constexpr int kSup = 256;         // codes per super-tile
-constexpr int kKC = 16;           // k per stage = one MFMA
-constexpr int kCodePlane = kSup * 32, kXPlane = kRows * 32;            // bytes per piece plane
-constexpr int kStageBytes = 3 * kCodePlane + 3 * kXPlane;              // 36864
-constexpr int kLdsBytes = 2 * kStageBytes + 2 * kSup * 4 + 2 * kRows * 4 + 2 * kRows * 8;
-
-__device__ __forceinline__ int swz(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
-
-__device__ __forceinline__ void split8(const float* v, bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 h1 = (__bf16)v[e];
-        const float r1 = v[e] - (float)h1;
-        const __bf16 h2 = (__bf16)r1;
-        const float r2 = r1 - (float)h2;
-        p1[e] = h1;
-        p2[e] = h2;
-        p3[e] = (__bf16)r2;
-    }
-}
 
 // tab: [nst][3][Kp][16] bf16, zero beyond (K, D); the two 16-byte halves of a row are stored in the order of the
 // kernel's LDS image (swapped on odd row octets), so a stage's slab is copied to LDS linearly

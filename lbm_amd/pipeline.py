@@ -42,6 +42,8 @@ class PipelineConfig:
                                        # (the 186 264 B/epoch compulsory figure excludes cleaned epochs)
     vq_method: str = "fp32"            # 'fp32': exact fmaf chain on the fp32 MFMA; 'bf16x6': fp32 products rebuilt from three
                                        # bf16 pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
+    conv_method: str = "fp32"          # 'bf16x6': the encoder's 256-channel layers (3rd conv, 1x1 projection) on the bf16 MFMA
+                                       # with three-piece operands (conv_bf16.hip; same accuracy vs float64 as the fp32 chain)
     fold_projection: bool = False      # tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook
                                        # (quantizer.fold_projection; no z output; equal tokens except fp32 near-ties)
 
@@ -84,6 +86,13 @@ class EpochPipeline:
             if cfg.vq_method == "bf16x6":
                 from .quantizer import vq_split_tables
                 self.vq_tab = vq_split_tables(self.cb_fold if cfg.fold_projection else self.codebook)
+            if cfg.conv_method not in ("fp32", "bf16x6"):
+                raise ValueError(f"conv_method {cfg.conv_method!r}")
+            self.conv_tab = {}
+            if cfg.conv_method == "bf16x6":
+                from .quantizer import conv_split_tables
+                for i in (4,) if cfg.fold_projection else (4, 6):
+                    self.conv_tab[i] = conv_split_tables(self.enc[f"encoder.{i}.weight"])
             T = cfg.n_times
             self.L1 = (T + 2 - 4) // 2 + 1
             self.L2 = (self.L1 + 2 - 4) // 2 + 1
@@ -167,9 +176,15 @@ class EpochPipeline:
             out["cleaned"] = base
         if c.do_tokenize:
             e = self.enc
-            conv = lambda xi, ldx, yo, ldy, i, cin, lin, cout, ks, s_, pd, relu: _lib.check(  # noqa: E731
-                lib.lbm_conv1d_pitched_f32(p(xi), ldx, p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin,
-                                           cout, ks, s_, pd, relu, st), "conv")
+
+            def conv(xi, ldx, yo, ldy, i, cin, lin, cout, ks, s_, pd, relu):
+                tab = self.conv_tab.get(i)
+                if tab is not None:
+                    _lib.check(lib.lbm_conv1d_bf16x6_f32(p(xi), ldx, p(tab), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin, cout,
+                                                         ks, s_, pd, relu, st), "conv(bf16x6)")
+                else:
+                    _lib.check(lib.lbm_conv1d_pitched_f32(p(xi), ldx, p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), ldy,
+                                                          E, cin, lin, cout, ks, s_, pd, relu, st), "conv")
             conv(B["std"], T, B["h1"], self.P1, 0, C, T, 64, 4, 2, 1, 1)
             t0 = mark("conv1", t0)
             conv(B["h1"], self.P1, B["h2"], self.P2, 2, 64, self.L1, 128, 4, 2, 1, 1)

@@ -175,10 +175,27 @@ def pitched_empty(B: int, Cc: int, L: int, device) -> torch.Tensor:
     return torch.empty((B, Cc, _pitch4(L)), dtype=torch.float32, device=device)[:, :, :L]
 
 
+def conv_split_tables(weight: torch.Tensor) -> torch.Tensor:
+    """Device table of conv weights [Cout, Cin, k] cut into three bf16 pieces per value (``lbm_conv1d_split_tables_init``),
+    the form ``conv1d(..., split_tables=...)`` / ``lbm_conv1d_bf16x6_f32`` consume."""
+    w = _lib.dev_f32(weight)
+    Cout, Cin, ks = w.shape
+    lib = _lib.load()
+    nbytes = lib.lbm_conv1d_split_tables_bytes(Cin, Cout, ks)
+    if nbytes == 0:
+        raise NotImplementedError(f"conv_split_tables: unsupported weight shape {tuple(w.shape)}")
+    tab = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.lbm_conv1d_split_tables_init(_lib.ptr(tab), _lib.ptr(w), Cin, Cout, ks, _lib.stream_ptr()),
+               "lbm_conv1d_split_tables_init")
+    return tab
+
+
 def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, stride: int = 1, padding: int = 0,
-           relu: bool = False, pitched_out: bool = False) -> torch.Tensor:
+           relu: bool = False, pitched_out: bool = False, split_tables: torch.Tensor = None) -> torch.Tensor:
     """nn.Conv1d (+ReLU) forward on fp32 MFMA.  x: [B, Cin, L] (contiguous or a pitched view); weight: [Cout, Cin, k].
-    ``pitched_out`` returns a [B, Cout, Lout] view of a row-padded buffer (what the next layer reads fastest)."""
+    ``pitched_out`` returns a [B, Cout, Lout] view of a row-padded buffer (what the next layer reads fastest).
+    ``split_tables`` (from ``conv_split_tables(weight)``) selects the bf16-piece kernel (fp32-grade products on the
+    bf16 matrix cores; results within fp32 rounding of the default kernel)."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
         x = _lib.dev_f32(x)
     x = _pitched_rows(x)
@@ -192,6 +209,11 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, str
     y = pitched_empty(B, Cout, Lout, x.device) if pitched_out else torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
     ldx = x.stride(1) if B * Cin > 1 else Lin
     ldy = y.stride(1) if B * Cout > 1 else Lout
+    if split_tables is not None:
+        _lib.check(_lib.load().lbm_conv1d_bf16x6_f32(_lib.ptr(x), ldx, _lib.ptr(split_tables), _lib.ptr(b), _lib.ptr(y), ldy, B, Cin,
+                                                     Lin, Cout, ks, stride, padding, int(relu), _lib.stream_ptr()),
+                   "lbm_conv1d_bf16x6_f32")
+        return y
     _lib.check(_lib.load().lbm_conv1d_pitched_f32(_lib.ptr(x), ldx, _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), ldy, B, Cin, Lin, Cout,
                                                   ks, stride, padding, int(relu), _lib.stream_ptr()), "lbm_conv1d_pitched_f32")
     return y

@@ -293,6 +293,31 @@ def test_conv1d_pitched_rows_bitwise_equal_dense(B, Cin, L, Cout, k, s, p):
     assert float((dense.double().cpu() - want).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 128, 375, 256, 3, 1, 1), (2, 256, 375, 256, 1, 1, 0), (2, 64, 750, 128, 4, 2, 1),
+                                                (3, 30, 1500, 64, 4, 2, 1), (2, 12, 130, 300, 3, 1, 1), (1, 20, 9, 7, 1, 1, 0),
+                                                (2, 7, 33, 70, 5, 3, 2)])
+def test_conv1d_bf16x6_matches_float64(B, Cin, L, Cout, k, s, p):
+    """lbm_conv1d_bf16x6_f32 (fp32 products rebuilt from three bf16 pieces): the fp32 kernels' tolerance against float64,
+    dense and pitched rows."""
+    from lbm_amd.quantizer import pitched_empty
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / math.sqrt(Cin * k)
+    b = torch.randn(Cout, generator=g)
+    tab = lbm_amd.conv_split_tables(w.to(DEV))
+    for relu in (False, True):
+        y = lbm_amd.conv1d(x.to(DEV), w.to(DEV), b.to(DEV), s, p, relu, split_tables=tab).cpu()
+        want = torch.nn.functional.conv1d(x.double(), w.double(), b.double(), stride=s, padding=p)
+        want = torch.relu(want) if relu else want
+        assert y.shape == want.shape
+        assert float((y.double() - want).abs().max()) <= 1e-5
+    xp = pitched_empty(B, Cin, L, DEV)
+    xp.copy_(x)
+    xp.as_strided((B, Cin, xp.stride(1)), xp.stride())[:, :, L:] = float("nan")
+    yp = lbm_amd.conv1d(xp, w.to(DEV), b.to(DEV), s, p, True, pitched_out=True, split_tables=tab)
+    assert torch.equal(yp.cpu(), y)
+
+
 # ------------------------------------------------------------------------------------------------ a12-a14 VQ
 def test_vq_golden_get_code_indices(shipped, vq_golden):
     cb = shipped["vq_layer.embedding.weight"]
@@ -569,6 +594,30 @@ def test_pipeline_bf16x6_quantizer_tokens(shipped):
     cb = shipped["vq_layer.embedding.weight"]
     assert (tok == tok_ref).mean() >= 0.999
     assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
+    assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_pipeline_bf16x6_convs(shipped, fold):
+    """conv_method='bf16x6': the 256-channel encoder layers on the bf16 MFMA.  z within fp32 rounding of the fp32-MFMA
+    path's z (both are ~1 ulp chains of the same products), tokens equal except documented near-ties."""
+    pipe, taps, A, b = _make_pipeline(shipped, T=1500)
+    cfg = lbm_amd.PipelineConfig(vq_method="bf16x6", conv_method="bf16x6", fold_projection=fold)
+    pipe2 = lbm_amd.EpochPipeline(cfg, taps, A, b, shipped, shipped["vq_layer.embedding.weight"])
+    x = (synth_epochs(48, 30, 1500, seed=35) * 2.0).to(DEV)
+    ref = pipe.run(x)
+    tok_ref, zr = ref["tokens"].cpu().numpy(), ref["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy().copy()
+    out = pipe2.run(x)
+    tok = out["tokens"].cpu().numpy()
+    cb = shipped["vq_layer.embedding.weight"]
+    assert (tok == tok_ref).mean() >= 0.998
+    if not fold:
+        z = out["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+        assert np.abs(z - zr).max() <= 2e-5 * np.abs(zr).max()
+        assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
+    else:
+        assert "z" not in out
+        assert orc.vq_near_tie_ok(zr, cb, tok.reshape(-1), tok_ref.reshape(-1)).all()
     assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
 
 

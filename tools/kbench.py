@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dense", action="store_true", help="conv stages: dense rows (pitch = length) instead of 16-byte rows")
     ap.add_argument("--samples", type=int, default=1_800_000, help="ica stages: recording length")
+    ap.add_argument("--split", action="store_true", help="conv stages: the bf16x6 kernel over pre-split weight tables")
     ap.add_argument("--cin", type=int, default=0, help="conv stages: override the input channel count (random weights)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -94,6 +95,9 @@ def main():
         xin = rnd(E, cin, ldx)
         yo = torch.empty(E, cout, ldy, device=dev)
         fn = lambda: lib.lbm_conv1d_pitched_f32(p(xin), ldx, p(wt), p(bs), p(yo), ldy, E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
+        if args.split:
+            ctab = lbm_amd.conv_split_tables(wt)
+            fn = lambda: lib.lbm_conv1d_bf16x6_f32(p(xin), ldx, p(ctab), p(bs), p(yo), ldy, E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
     elif s in ("fir", "fir_direct"):
         taps = torch.as_tensor(lbm_amd.create_filter(500.0, 4.0, 30.0)).to(dev, torch.float32)
         if s == "fir":
