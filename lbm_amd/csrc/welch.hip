@@ -276,10 +276,7 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
                 o.bs = *reinterpret_cast<const float4*>(bb + 4 * n);
                 return o;
             };
-            Ops cur = load_ops(0);
-            for (int t = 0; t < g.QS; ++t) {
-                const Ops nxt = load_ops(t + 1 < g.QS ? t + 1 : t);
-                __builtin_amdgcn_sched_barrier(0);   // keep the next step's LDS reads ahead of this step's VALU/MFMA
+            auto step_generic = [&](const Ops& cur) {
                 const float d1 = cur.d1 - m, d3 = cur.d3 - m;
                 float d2 = cur.d2 - m, d4 = cur.d4 - m;
                 if (cur.nc == 0) { d2 = 0.f; d4 = 0.f; }
@@ -291,8 +288,57 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(se, cur.bs.y, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(co, cur.bs.z, acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(so, cur.bs.w, acc[3], 0, 0, 0);
-                cur = nxt;
+            };
+            // Steps 1 .. QS-2 have 0 < n < Q on every lane: no clamps, no special terms, and the mean leaves the
+            // difference terms -- a1 = w1 (d1 + d2 - 2m), b1 = w1 (d1 - d2).  They run two at a time from running
+            // pointers (ascending ones at the pair's first step, descending ones at its second, so that both
+            // steps are immediate offsets), each step's operands requested while the other step computes.
+            struct Fast { float d1, d2, d3, d4, w1, w2; float4 bs; };
+            const float m2 = 2.f * m;
+            auto step_fast = [&](const Fast& o) {
+                const float a1 = o.w1 * ((o.d1 + o.d2) - m2), a2 = o.w2 * ((o.d3 + o.d4) - m2);
+                const float b1 = o.w1 * (o.d1 - o.d2), b2 = o.w2 * (o.d3 - o.d4);
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1 + a2, o.bs.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1 - b2, o.bs.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1 - a2, o.bs.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1 + b2, o.bs.w, acc[3], 0, 0, 0);
+            };
+            step_generic(load_ops(0));
+            int t = 1;
+            const int t_end = g.QS - 1;
+            if (t + 2 <= t_end) {
+                const int n1 = 4 + kq;                      // n of step 1
+                const float* p1 = base + n1;                // base[n]
+                const float* p4 = base + g.H + n1;          // base[H + n]
+                const float* pw1 = s_win + n1;              // win[n]
+                const float* pb = bb + 4 * n1;              // basis[n]
+                const float* q3 = base + g.H - n1 - 4;      // base[H - n] of the pair's second step
+                const float* q2 = base + g.N - n1 - 4;      // base[N - n]
+                const float* qw2 = s_win + g.H - n1 - 4;    // win[H - n]
+                auto load_a = [&]() {
+                    Fast o;
+                    o.d1 = p1[0]; o.d4 = p4[0]; o.w1 = pw1[0]; o.d3 = q3[4]; o.d2 = q2[4]; o.w2 = qw2[4];
+                    o.bs = *reinterpret_cast<const float4*>(pb);
+                    return o;
+                };
+                auto load_b = [&]() {
+                    Fast o;
+                    o.d1 = p1[4]; o.d4 = p4[4]; o.w1 = pw1[4]; o.d3 = q3[0]; o.d2 = q2[0]; o.w2 = qw2[0];
+                    o.bs = *reinterpret_cast<const float4*>(pb + 16);
+                    return o;
+                };
+                Fast A = load_a();
+                for (; t + 2 <= t_end; t += 2) {
+                    const Fast B = load_b();
+                    p1 += 8; p4 += 8; pw1 += 8; pb += 32; q3 -= 8; q2 -= 8; qw2 -= 8;
+                    __builtin_amdgcn_sched_barrier(0);
+                    step_fast(A);
+                    A = load_a();   // the next pair's first step (after the last pair: an in-range read nobody uses)
+                    __builtin_amdgcn_sched_barrier(0);
+                    step_fast(B);
+                }
             }
+            for (; t < g.QS; ++t) step_generic(load_ops(t));
             // accumulator: column = bin slot j (lane & 15), rows = segments 4*kq + r
             const int ie = ke0 + 2 * j - bin_lo, io = ko0 + 2 * j - bin_lo;
 #pragma unroll
