@@ -134,7 +134,7 @@ __host__ __device__ inline FoldGeom fold_geom(int nfft, int T, int hop, int nseg
     return g;
 }
 
-__global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __restrict__ x, float* __restrict__ psd, int64_t rows,
+__global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict__ x, float* __restrict__ psd, int64_t rows,
                                                               int T, double fs, FoldGeom g, const void* __restrict__ tables,
                                                               int bin_lo, int F, int64_t ngroups) {
     extern __shared__ __align__(16) float smem[];
@@ -235,9 +235,20 @@ __global__ __launch_bounds__(kThreads) void welch_fold_kernel(const float* __res
             const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int n = 8 * part;
-            for (; n + 8 <= g.N; n += 32) {
+            if (((T | g.hop) & 1) == 0) {   // 8-byte aligned segments: half the LDS instructions
+                for (; n + 8 <= g.N; n += 32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += base[n + u];
+                    for (int u = 0; u < 4; ++u) {
+                        const float2 v = *reinterpret_cast<const float2*>(base + n + 2 * u);
+                        acc[2 * u] += v.x;
+                        acc[2 * u + 1] += v.y;
+                    }
+                }
+            } else {
+                for (; n + 8 <= g.N; n += 32) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] += base[n + u];
+                }
             }
             if (n < g.N) {   // ragged tail group of this lane
 #pragma unroll
@@ -514,8 +525,8 @@ extern "C" int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int
         n_odd <= 16 && nseg >= 1) {
         const FoldGeom g = fold_geom(nfft, T, hop, nseg);
         const size_t shared_floats = (size_t)16 * g.LDB + ((g.H + 1 + 3) & ~3);
-        int waves = 4;
-        while (waves > 1 && (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float) > 160 * 1024) waves >>= 1;
+        int waves = 6;   // 2 + 2 + 1 + 1 per SIMD: the phases of a group are chains of LDS round trips, other waves fill them
+        while (waves > 1 && (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float) > 160 * 1024) --waves;
         const size_t lds_f = (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float);
         if (lds_f <= 160 * 1024) {
             const int64_t ngroups = (rows + g.RW - 1) / g.RW;
