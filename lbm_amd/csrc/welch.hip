@@ -158,6 +158,8 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
     const double scale = 1.0 / (fs * (*tv.sum_w2));
     const int waves_per_block = blockDim.x >> 6;
     const float inv_n = 1.f / (float)g.N;
+    const float inv_F = 1.f / (float)F;
+    const double scale2 = scale * 2.0;
     const int ke0 = bin_lo + (bin_lo & 1), ko0 = bin_lo + 1 - (bin_lo & 1);
 
     // Row staging.  With one wavefront per SIMD nothing hides an HBM round trip, so the NEXT group's rows are
@@ -236,6 +238,16 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int n = 8 * part;
             if (((T | g.hop) & 1) == 0) {   // 8-byte aligned segments: half the LDS instructions
+                for (; n + 104 <= g.N; n += 128) {   // four groups per trip: 16 reads in flight, not 4
+                    float2 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float2*>(base + n + 32 * (u >> 2) + 2 * (u & 3));
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        acc[2 * (u & 3)] += v[u].x;
+                        acc[2 * (u & 3) + 1] += v[u].y;
+                    }
+                }
                 for (; n + 8 <= g.N; n += 32) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -363,12 +375,12 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
         // ---- segment average (ascending segment order) and scaling; outputs of the group are contiguous
         const int nout = nrows * F;
         for (int o = lane; o < nout; o += 64) {
-            const int r = o / F, fb = o - r * F;
+            const int r = (int)(((float)o + 0.5f) * inv_F), fb = o - r * F;   // o / F (exact: o < 16 F, F < 2^10)
             float acc = 0.f;
             for (int s = 0; s < g.nseg; ++s) acc += s_P[(r * g.nseg + s) * kLdp + fb];
             const int k = bin_lo + fb;
-            const double one_sided = (k == 0 || k == g.H) ? 1.0 : 2.0;
-            psd[row0 * F + o] = (float)((double)(acc / (float)g.nseg) * (scale * one_sided));
+            const double sc = (k == 0 || k == g.H) ? scale : scale2;
+            psd[row0 * F + o] = (float)((double)(acc / (float)g.nseg) * sc);
         }
         __builtin_amdgcn_wave_barrier();
     }
