@@ -167,6 +167,128 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
     }
 }
 
+// D = 256, K a multiple of 64, 16-byte aligned codebook: the same arithmetic (same ascending fmaf chains, same argmin
+// rule) with the tile traffic off the critical path.  8 waves (256 input rows) share each 64-code tile; the tiles are
+// double buffered in LDS and filled by LDS-DMA (global_load_lds_dwordx4: one wave-instruction = one 1 KiB code row
+// dropped at its padded LDS row, no staging registers, no ds_write), tile t+1 requested before tile t's MFMA stream
+// and awaited after it: one barrier per tile and no exposed L2 round trip.  |e|^2 of the tile rides the same way.
+constexpr int kDmaThreads = 512;
+constexpr int kDmaRows = 256;
+constexpr int kDmaLDE = 256 + 4;
+constexpr int kDmaBufFloats = kTileCodes * kDmaLDE + kTileCodes;
+
+template <int LAYOUT>
+__global__ __launch_bounds__(kDmaThreads) void vq_argmin_dma_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                    const float* __restrict__ codebook,
+                                                                    const float* __restrict__ e_sqnorm,
+                                                                    int64_t* __restrict__ idx_out, float* __restrict__ mind,
+                                                                    int64_t N, int K, int vec_ok, int64_t S, int no_xnorm) {
+    constexpr int D = 256, HALF = 128, LDE = kDmaLDE;
+    extern __shared__ __align__(16) float smem[];   // [2][ 64 x LDE tile | 64 |e|^2 ]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t row = (int64_t)blockIdx.x * kDmaRows + wave * 32 + j;
+    const int64_t row_c = row < N ? row : N - 1;
+
+    // tile -> LDS: wave w copies code rows 8w .. 8w+7 of the tile; wave 0 also the 64 |e|^2
+    auto copy_tile = [&](int kbase, int buf) {
+        float* dst = smem + buf * kDmaBufFloats;
+        const float* src = codebook + (int64_t)(kbase + wave * 8) * D + lane * 4;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * D),
+                                             (__attribute__((address_space(3))) void*)(dst + (wave * 8 + r) * LDE), 16, 0, 0);
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(e_sqnorm + kbase + lane),
+                                             (__attribute__((address_space(3))) void*)(dst + kTileCodes * LDE), 4, 0, 0);
+    };
+
+    // ---- B fragments: this lane's half of its input row
+    float bx[HALF];
+    if constexpr (LAYOUT == LBM_VQ_ROWS) {
+        const float* p = x + row_c * ldx + h * HALF;
+        if (vec_ok) {
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) {
+                const float4 v = reinterpret_cast<const float4*>(p)[q];
+                bx[4 * q] = v.x; bx[4 * q + 1] = v.y; bx[4 * q + 2] = v.z; bx[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < HALF; ++s) bx[s] = p[s];
+        }
+    } else {
+        const int64_t b = row_c / S, sp = row_c - b * S;
+        const float* p = x + (b * D + h * HALF) * ldx + sp;
+        const int ld = (int)ldx;   // D * ldx < 2^31 is checked by the launcher
+#pragma unroll
+        for (int s = 0; s < HALF; ++s) bx[s] = p[s * ld];
+    }
+    copy_tile(0, 0);
+    float xx = 0.f;
+#pragma unroll
+    for (int s = 0; s < HALF; ++s) xx = fmaf(bx[s], bx[s], xx);
+    xx += __shfl_xor(xx, 32, 64);
+    if (no_xnorm) xx = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float best = INFINITY;
+    int bidx = 0;
+    int buf = 0;
+    for (int kbase = 0; kbase < K; kbase += kTileCodes, buf ^= 1) {
+        if (kbase + kTileCodes < K) copy_tile(kbase + kTileCodes, buf ^ 1);   // its last readers passed the barrier below
+        const float* s_e = smem + buf * kDmaBufFloats;
+        const float* s_ee = s_e + kTileCodes * LDE;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = 0.f;
+            acc1[r] = 0.f;
+        }
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const unsigned char* ap0 = reinterpret_cast<const unsigned char*>(smem) + (buf * kDmaBufFloats + j * LDE + h * HALF) * 4;
+        const unsigned char* ap1 = ap0 + 32 * LDE * 4;
+#pragma unroll
+        for (int q = 0; q < HALF / 4; ++q) {
+            const f4 a0 = *reinterpret_cast<const f4*>(ap0 + 16 * q);
+            const f4 a1 = *reinterpret_cast<const f4*>(ap1 + 16 * q);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bx[4 * q + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bx[4 * q + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bx[4 * q + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bx[4 * q + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bx[4 * q + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bx[4 * q + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bx[4 * q + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bx[4 * q + 3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float dist = (xx + s_ee[cl]) - 2.f * (c == 0 ? acc0[r] : acc1[r]);
+                if (dist < best) {
+                    best = dist;
+                    bidx = kbase + cl;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows this wave copied for the next tile have landed
+        __syncthreads();
+    }
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oi = __shfl_xor(bidx, 32, 64);
+    if (ob < best || (ob == best && oi < bidx)) {
+        best = ob;
+        bidx = oi;
+    }
+    if (h == 0 && row < N) {
+        idx_out[row] = (int64_t)bidx;
+        if (mind != nullptr) mind[row] = best;
+    }
+}
+
 // usage histogram of int64 indices: LDS-privatised bins, one 64-bit atomic per non-empty bin per block
 __global__ __launch_bounds__(256) void hist_kernel(const int64_t* __restrict__ idx, unsigned long long* __restrict__ hist,
                                                    int64_t N, int K) {
@@ -265,6 +387,20 @@ int launch_vq(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, 
     return lbm::check_launch("lbm_vq_argmin_f32");
 }
 
+int launch_vq_dma(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, const float* codebook, const float* e_sqnorm,
+                  int64_t* idx_out, float* mind, int64_t N, int K, hipStream_t st) {
+    const size_t lds = (size_t)2 * kDmaBufFloats * sizeof(float);
+    const int64_t blocks = (N + kDmaRows - 1) / kDmaRows;
+    if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: grid too large");
+    const int vec_ok = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
+    auto k = layout == LBM_VQ_ROWS ? vq_argmin_dma_kernel<LBM_VQ_ROWS> : vq_argmin_dma_kernel<LBM_VQ_CHANNEL_MAJOR>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kDmaThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, K, vec_ok, S,
+                       no_xnorm);
+    return lbm::check_launch("lbm_vq_argmin_f32");
+}
+
 }  // namespace
 
 // shared with vq_bf16.hip
@@ -307,6 +443,9 @@ extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, in
     int rc;
     if (D <= 64) rc = launch_vq<64>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
     else if (D <= 128) rc = launch_vq<128>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
+    else if (D == 256 && (K % kTileCodes) == 0 && ((uintptr_t)e_sqnorm & 3) == 0 &&
+             (layout == LBM_VQ_ROWS || (int64_t)D * ldx < 0x7fffffffLL))
+        rc = launch_vq_dma(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, K, st);
     else rc = launch_vq<256>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, mind_or_null, N, D, K, st);
     if (rc != LBM_OK) return rc;
     if (hist_or_null != nullptr) {
