@@ -240,6 +240,19 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # the exchange step alone ("report gather time separately"), outside the timed region
+    gather_ms = None
+    if gathered is not None and args.backend == "nccl":
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        dist.all_gather_into_tensor(gathered.view(torch.uint8), tokens.view(torch.uint8))
+        dist.all_reduce(pipe._buf["hist"])
+        g1.record()
+        torch.cuda.synchronize()
+        gather_ms = round(g0.elapsed_time(g1), 3)
+
     # per-kernel durations from HIP events recorded on the launch stream (one chunk, outside the timed region)
     stages = {}
     if rank == 0:
@@ -323,6 +336,7 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "stages": stages,
+            "gather_ms_per_step": gather_ms,
             "variants": variants,
         }
         print(json.dumps(line))
