@@ -64,9 +64,27 @@ def cpu_baseline(taps, A, b, weights, sample_epochs):
     for lo in range(0, sample_epochs, 256):
         orc.pipeline(x[lo:lo + 256], 500.0, taps, A, b, 251, 150e-6, weights, fft_filter=True)
     dt = time.perf_counter() - t0
+    # per-stage rates of the same restatement on one 256-epoch block (beside the GPU stage numbers)
+    n = min(256, sample_epochs)
+    xs = np.asarray(x[:n], dtype=np.float64)
+    per = {}
+
+    def timed(name, fn):
+        t = time.perf_counter()
+        r = fn()
+        per[name] = round(n / (time.perf_counter() - t), 1)
+        return r
+    y = timed("fir", lambda: orc.fir_zero_phase(xs, taps, fft=True))
+    y = timed("affine", lambda: np.einsum("oc,ect->eot", np.asarray(A, dtype=np.float64), y) + np.asarray(b, dtype=np.float64)[None, :, None])
+    std = timed("post", lambda: (orc.ptp_keep_mask(orc.baseline_correct(y, 251), 150e-6), orc.zscore_epoch_channel(y, 1e-6))[1])
+    timed("welch", lambda: orc.welch_psd(y, 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann"))
+    h = timed("encoder", lambda: orc.encoder_forward(std.astype(np.float32), weights))
+    flat = np.ascontiguousarray(np.transpose(np.asarray(h), (0, 2, 1))).reshape(-1, np.asarray(h).shape[1])
+    timed("vq", lambda: orc.vq_argmin(flat, weights["vq_layer.embedding.weight"]))
     return {"value": round(sample_epochs / dt, 1), "unit": "epochs/s", "cores": cores, "kind": "port",
             "sample": f"{sample_epochs} synthetic 30x1500 epochs through oracle/eeg_oracle.pipeline "
-                      f"(float64 scipy FIR(oaconvolve)/ICA/Welch + torch-CPU fp32 encoder+VQ), {dt:.1f} s"}
+                      f"(float64 scipy FIR(oaconvolve)/ICA/Welch + torch-CPU fp32 encoder+VQ), {dt:.1f} s",
+            "stage_epochs_per_s": per}
 
 
 def alloc_resident(E, C, T, dev, reserve_bytes):
