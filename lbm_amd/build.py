@@ -39,11 +39,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     obj_dir = os.path.join(HERE, "csrc", "_obj")
     os.makedirs(obj_dir, exist_ok=True)
     flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+    # The FFT kernels keep complex values as split re/im registers; the SLP vectorizer pairs them into packed-fp32 ops
+    # and pays for it with register moves (fir_fft_kernel: 384 v_mov per item, 16 B of scratch; 3.9 -> 3.2 ms without).
+    no_slp = {"fir_fft.hip", "welch.hip", "resample.hip"}
     procs = []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        cmd = [_hipcc(), *flags, "-c", src, "-o", obj]
+        extra = ["-fno-slp-vectorize"] if os.path.basename(src) in no_slp else []
+        cmd = [_hipcc(), *flags, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
