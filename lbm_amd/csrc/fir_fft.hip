@@ -83,10 +83,10 @@ __global__ void fir_fft_tables_kernel(float2* __restrict__ tab, const float* __r
 // NSUB independent items per workgroup (NSUB * N/16 threads): the sub-groups share the stage-1 twiddle table
 // and the barriers, which raises the waves per CU that fit next to the LDS (12 instead of 8 at N = 2048).
 // NPF: 16-byte quads per thread that cover one window's real samples (min(T, Lb + N) / 4 / (N/16), <= 8).
-template <int R3, int NPF, int NSUB>
+template <int R3, int NPF, int NSUB, bool VEC>
 __global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_kernel(const float* __restrict__ x, float* __restrict__ y, int T,
-                                                          int ntaps, int pad_mode, int npairs, int Lb, long long items,
-                                                          const float2* __restrict__ tab, int vec) {
+                                                          int ntaps, int pad_mode, int npairs, int Lb, int items,
+                                                          const float2* __restrict__ tab) {
     constexpr int Q = 16 * R3, N = 16 * Q, NT = Q, G = 16 / R3;
     constexpr int A1S = Q + R3;          // stage-1 <-> stage-2 exchange: element (k1, j) at k1*A1S + j
     constexpr int A2S = 272 + 16 / R3;   // stage-2 <-> stage-3 exchange: element (k1, k2, n3) at n3*A2S + 17 k1 + k2
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_ke
     float2* s_t1 = fft_smem;             // [k1][j]  w_N^{j k1}
     float2* s_t2 = s_t1 + N;             // [k2][n3] w_Q^{n3 k2}
     constexpr int XCH = (16 * A1S > R3 * A2S) ? 16 * A1S : R3 * A2S;
-    const int t = threadIdx.x % NT, sub = threadIdx.x / NT;
+    const int t = threadIdx.x % NT;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // NT is a multiple of 64: wave-uniform, so the
+                                                                         // item arithmetic below stays on the scalar unit
     float2* s_x = s_t2 + Q + sub * XCH;  // [XCH] per sub-group
 
     for (int i = threadIdx.x; i < N; i += NT * NSUB) s_t1[i] = tab[N + i];
@@ -122,15 +124,15 @@ __global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_ke
     float* const P = reinterpret_cast<float*>(s_x);
     const int WL = Lb + N;               // LDS floats a transform pair reads
     float4 pre[NPF];
-    auto window_start = [&](long long item) { return 2 * (int)(item % npairs) * Lb - half; };
-    auto prefetch = [&](long long item) {
-        const float* xr = x + (item / npairs) * (long long)T;
+    auto window_start = [&](int item) { return 2 * (int)((unsigned)item % (unsigned)npairs) * Lb - half; };
+    auto prefetch = [&](int item) {
+        const float* xr = x + (long long)((unsigned)item / (unsigned)npairs) * T;
         const int ms = window_start(item);
         const int q0 = ms < 0 ? 0 : (ms & ~3);              // first sample of quad 0 (16-byte aligned when vec)
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int m = q0 + 4 * (t + NT * i);
-            if (vec) {
+            if constexpr (VEC) {
                 pre[i] = *reinterpret_cast<const float4*>(xr + (m + 3 < T ? m : 0));
             } else {
                 pre[i] = make_float4(xr[m < T ? m : 0], xr[m + 1 < T ? m + 1 : 0], xr[m + 2 < T ? m + 2 : 0],
@@ -139,14 +141,14 @@ __global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_ke
         }
     };
     // every sub-group runs every iteration (shared barriers); one past the end re-does the last item, stores off
-    const long long first = (long long)blockIdx.x * NSUB + sub;
+    const int first = blockIdx.x * NSUB + sub;
     prefetch(first < items ? first : items - 1);
 
-    for (long long base = (long long)blockIdx.x * NSUB; base < items; base += (long long)gridDim.x * NSUB) {
+    for (int base = blockIdx.x * NSUB; base < items; base += gridDim.x * NSUB) {   // items + grid * NSUB < 2^31 (launcher)
         const bool active = base + sub < items;
-        const long long item = active ? base + sub : items - 1;
-        const long long row = item / npairs;
-        const int pair = (int)(item % npairs);
+        const int item = active ? base + sub : items - 1;
+        const long long row = (unsigned)item / (unsigned)npairs;
+        const int pair = (int)((unsigned)item % (unsigned)npairs);
         const int a0 = 2 * pair * Lb, b0 = a0 + Lb;
         const bool has_b = b0 < T;
         const int ms = a0 - half;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_ke
 
         // ---- real samples -> LDS (sample m sits at P[m - ms]); vec: T % 4 == 0, so a quad never straddles the row end
         __syncthreads();   // the previous item's last exchange reads are done
-        const bool st4 = vec && !(ms & 3);
+        const bool st4 = VEC && !(ms & 3);
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             float4 v = pre[i];
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(16 * R3 * NSUB, (R3 == 16 ? 2 : 3)) void fir_fft_ke
         }
         __syncthreads();   // the window is consumed; s_x becomes the exchange buffer
         {   // next item's loads fly under this item's transforms (the last item re-reads itself, unused)
-            const long long nxt = base + (long long)gridDim.x * NSUB + sub;
+            const int nxt = base + gridDim.x * NSUB + sub;
             prefetch(nxt < items ? nxt : items - 1);
         }
 
@@ -327,14 +329,13 @@ int launch_fir_k(const float* x, float* y, int64_t rows, int T, int ntaps, int p
     long long grid = 256LL * per_cu;
     const long long need = (items + NSUB - 1) / NSUB;
     if (grid > need) grid = need;
-    auto k = fir_fft_kernel<R3, NPF, NSUB>;
+    const bool vec = (T % 4 == 0) && (((uintptr_t)x & 15) == 0);   // every row starts 16-byte aligned
+    auto k = vec ? fir_fft_kernel<R3, NPF, NSUB, true> : fir_fft_kernel<R3, NPF, NSUB, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_fir_fft_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    const int vec = (T % 4 == 0) && (((uintptr_t)x & 15) == 0);   // every row starts 16-byte aligned
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(16 * R3 * NSUB), lds, s, x, y, T, ntaps, pad_mode, p.npairs, p.Lb, items, tab,
-                       vec);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(16 * R3 * NSUB), lds, s, x, y, T, ntaps, pad_mode, p.npairs, p.Lb, (int)items, tab);
     return lbm::check_launch("lbm_fir_fft_f32");
 }
 
@@ -384,7 +385,7 @@ extern "C" int lbm_fir_fft_f32(const float* x, float* y, int64_t rows, int32_t T
     FftPlan p;
     LBM_REQUIRE(make_plan(T, ntaps, &p), LBM_EUNSUPPORTED,
                 "lbm_fir_fft_f32: ntaps=%d does not fit a 4096-point transform (use lbm_fir_f32)", ntaps);
-    LBM_REQUIRE((long long)rows * p.npairs <= 0x7fffffffffffLL, LBM_EUNSUPPORTED, "lbm_fir_fft_f32: too many rows");
+    LBM_REQUIRE((long long)rows * p.npairs <= 0x7ff00000LL, LBM_EUNSUPPORTED, "lbm_fir_fft_f32: too many rows (rows x block pairs must stay below 2^31)");
     const float2* tab = static_cast<const float2*>(tables);
     hipStream_t s = lbm::as_stream(stream);
     if (p.R3 == 4) return launch_fir<4, 2>(x, y, rows, T, ntaps, pad_mode, p, tab, s);
