@@ -47,6 +47,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         extra = ["-fno-slp-vectorize"] if os.path.basename(src) in no_slp else []
+        if os.path.basename(src) == "vq.hip":   # 12.23 -> 12.04 ms on the quantizer (A/B x3); neutral on the conv kernels
+            extra += ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
         cmd = [_hipcc(), *flags, *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
