@@ -359,6 +359,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()   # rank 0 measured the per-stage events and variants alone: leave together
         dist.destroy_process_group()
 
 
