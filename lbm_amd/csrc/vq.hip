@@ -203,41 +203,47 @@ __global__ __launch_bounds__(kDmaThreads) void vq_argmin_dma_kernel(const float*
                                              (__attribute__((address_space(3))) void*)(dst + kTileCodes * LDE), 4, 0, 0);
     };
 
-    // ---- B fragments: this lane's half of its input row
+    // ---- B fragments: this lane's half of its input row.  Only the first half of it is loaded before the first
+    // barrier; the second half is requested at the top of the first tile and consumed by the second half of that
+    // tile's MFMA stream (with one workgroup per CU nothing else would hide the row load).
     float bx[HALF];
-    if constexpr (LAYOUT == LBM_VQ_ROWS) {
-        const float* p = x + row_c * ldx + h * HALF;
-        if (vec_ok) {
+    auto load_x = [&](int s0, int s1) {
+        if constexpr (LAYOUT == LBM_VQ_ROWS) {
+            const float* p = x + row_c * ldx + h * HALF;
+            if (vec_ok) {
 #pragma unroll
-            for (int q = 0; q < HALF / 4; ++q) {
-                const float4 v = reinterpret_cast<const float4*>(p)[q];
-                bx[4 * q] = v.x; bx[4 * q + 1] = v.y; bx[4 * q + 2] = v.z; bx[4 * q + 3] = v.w;
+                for (int q = s0 / 4; q < s1 / 4; ++q) {
+                    const float4 v = reinterpret_cast<const float4*>(p)[q];
+                    bx[4 * q] = v.x; bx[4 * q + 1] = v.y; bx[4 * q + 2] = v.z; bx[4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int s = s0; s < s1; ++s) bx[s] = p[s];
             }
         } else {
+            const int64_t b = row_c / S, sp = row_c - b * S;
+            const float* p = x + (b * D + h * HALF) * ldx + sp;
+            const int ld = (int)ldx;   // D * ldx < 2^31 is checked by the launcher
 #pragma unroll
-            for (int s = 0; s < HALF; ++s) bx[s] = p[s];
+            for (int s = s0; s < s1; ++s) bx[s] = p[s * ld];
         }
-    } else {
-        const int64_t b = row_c / S, sp = row_c - b * S;
-        const float* p = x + (b * D + h * HALF) * ldx + sp;
-        const int ld = (int)ldx;   // D * ldx < 2^31 is checked by the launcher
-#pragma unroll
-        for (int s = 0; s < HALF; ++s) bx[s] = p[s * ld];
-    }
+    };
+    load_x(0, HALF / 2);
     copy_tile(0, 0);
-    float xx = 0.f;
-#pragma unroll
-    for (int s = 0; s < HALF; ++s) xx = fmaf(bx[s], bx[s], xx);
-    xx += __shfl_xor(xx, 32, 64);
-    if (no_xnorm) xx = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    float xx = 0.f;
 
     float best = INFINITY;
     int bidx = 0;
-    int buf = 0;
-    for (int kbase = 0; kbase < K; kbase += kTileCodes, buf ^= 1) {
+    // one 64-code tile; the first call is peeled out of the loop below (hipcc drains vmcnt in a loop preheader when the
+    // loop consumes registers loaded before it -- that would put the whole row load back in front of the first tile)
+    auto do_tile = [&](const int kbase, const int buf) {
         if (kbase + kTileCodes < K) copy_tile(kbase + kTileCodes, buf ^ 1);   // its last readers passed the barrier below
+        if (kbase == 0) {
+            load_x(HALF / 2, HALF);
+            __builtin_amdgcn_sched_barrier(0);   // all 64 requests go out here, not next to their uses
+        }
         const float* s_e = smem + buf * kDmaBufFloats;
         const float* s_ee = s_e + kTileCodes * LDE;
         f32x16 acc0, acc1;
@@ -262,6 +268,11 @@ __global__ __launch_bounds__(kDmaThreads) void vq_argmin_dma_kernel(const float*
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bx[4 * q + 3], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bx[4 * q + 3], acc1, 0, 0, 0);
         }
+        if (kbase == 0 && !no_xnorm) {   // |x|^2, after the first tile's products so that it does not wait for the row up front
+#pragma unroll
+            for (int s = 0; s < HALF; ++s) xx = fmaf(bx[s], bx[s], xx);
+            xx += __shfl_xor(xx, 32, 64);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -276,7 +287,10 @@ __global__ __launch_bounds__(kDmaThreads) void vq_argmin_dma_kernel(const float*
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows this wave copied for the next tile have landed
         __syncthreads();
-    }
+    };
+    do_tile(0, 0);
+    for (int kbase = kTileCodes, buf = 1; kbase < K; kbase += kTileCodes, buf ^= 1) do_tile(kbase, buf);
+
     const float ob = __shfl_xor(best, 32, 64);
     const int oi = __shfl_xor(bidx, 32, 64);
     if (ob < best || (ob == best && oi < bidx)) {
