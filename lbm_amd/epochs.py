@@ -128,8 +128,17 @@ class Scaler:
         self.scale_ = (std if self.with_std else torch.ones_like(std)).to(torch.float32)
         return self
 
-    def fit(self, x: torch.Tensor, y=None):
-        return self.fit_from_moments(self.moments(x))
+    def fit(self, x: torch.Tensor, y=None, keep: Optional[torch.Tensor] = None, group=None):
+        """Per-channel statistics of this rank's epochs; with torch.distributed initialised the {sum, sum of squares,
+        count} block is all-reduced first, so every rank fits the statistics of the whole job."""
+        return self.fit_from_moments(self.reduce_moments(self.moments(x, keep), group))
+
+    @staticmethod
+    def reduce_moments(mom: torch.Tensor, group=None) -> torch.Tensor:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=group)
+        return mom
 
     def transform(self, x: torch.Tensor) -> torch.Tensor:
         x = _lib.dev_f32(x)

@@ -30,6 +30,16 @@ def _worker(rank, world, port, E, out_dir):
         hist = allreduce_hist(hist)
         ok = torch.equal(tok, tokens_all) and torch.equal(ft, feats_all) and \
             torch.equal(hist, torch.bincount(tokens_all.reshape(-1) % 7, minlength=7))
+        # Scaler-style global standardisation: all-reduced {sum, sum of squares, count} -> the statistics of the whole job
+        from lbm_amd.epochs import Scaler
+        g = torch.Generator().manual_seed(5)
+        xs = torch.randn(E, 3, 11, generator=g, dtype=torch.float64) * torch.tensor([1.0, 2.0, 0.5]).view(1, 3, 1) + 0.25
+        mine = xs[lo:hi]
+        mom = torch.stack([mine.sum(dim=(0, 2)), (mine * mine).sum(dim=(0, 2)),
+                           torch.full((3,), float(mine.shape[0] * mine.shape[2]), dtype=torch.float64)], dim=1)
+        sc = Scaler().fit_from_moments(Scaler.reduce_moments(mom))
+        ok = ok and torch.allclose(sc.mean_.double(), xs.mean(dim=(0, 2)), atol=1e-6) and \
+            torch.allclose(sc.scale_.double(), xs.std(dim=(0, 2), unbiased=False), atol=1e-6)
         np.save(os.path.join(out_dir, f"ok{rank}.npy"), np.array([int(ok), perplexity_from_counts(hist)]))
     finally:
         dist.destroy_process_group()
