@@ -670,6 +670,34 @@ def test_pipeline_full_size_properties(shipped):
     assert bool(torch.isfinite(o1["psd"]).all()) and bool((o1["psd"] > 0).all())
 
 
+def test_vq_full_size_every_row_is_a_minimum(shipped):
+    """The quantizer at the bench's launch size (16384 x 375 rows, channel-major, K = 512: the LDS-DMA kernel): every
+    returned code attains the row's minimum distance within the near-tie band, recomputed with torch on the GPU;
+    rows in ragged tail blocks (N not a multiple of 256) included; the ROWS layout gives the same tokens."""
+    E, S, D = 16384, 375, 256
+    cb = torch.from_numpy(shipped["vq_layer.embedding.weight"]).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(21)
+    z = torch.randn(E, D, 376, device=DEV, generator=g) * 0.05
+    tok = lbm_amd.vq_argmin(z[:, :, :S], cb, channel_major=True)
+    assert tok.shape == (E * S,) or tok.shape == (E, S)
+    tok = tok.reshape(E, S)
+    ee = (cb.double() ** 2).sum(1)
+    eps = 2.0 ** -23
+    bad = 0
+    for lo in range(0, E, 1024):
+        zc = z[lo:lo + 1024, :, :S].permute(0, 2, 1).reshape(-1, D).double()
+        d = (zc * zc).sum(1, keepdim=True) + ee[None, :] - 2.0 * (zc @ cb.double().t())
+        dmin = d.min(dim=1).values
+        dgot = d.gather(1, tok[lo:lo + 1024].reshape(-1, 1)).squeeze(1)
+        tol = 8 * eps * ((zc * zc).sum(1) + ee.max() + 2.0 * (zc.abs() @ cb.double().abs().t()).max(dim=1).values)
+        bad += int((dgot - dmin > tol).sum())
+    assert bad == 0
+    # ragged N and the row-major layout: same codes as the channel-major launch
+    flat = z[:3, :, :S].permute(0, 2, 1).reshape(-1, D).contiguous()[:1001]
+    t2 = lbm_amd.vq_argmin(flat, cb)
+    assert torch.equal(t2.reshape(-1), tok[:3].reshape(-1)[:1001])
+
+
 # ------------------------------------------------------------------------------------------------ 8(f)-4 resample
 @pytest.mark.parametrize("T,up,down,rows", [(5000, 1, 2, 3), (1001, 1, 2, 2), (30000, 250, 1000, 2), (65539, 250, 500, 1), (3000, 2, 1, 2),
                                             (70, 1, 2, 1), (300000, 1, 2, 70)])
