@@ -227,6 +227,30 @@ def test_welch_average_modes_and_errors():
     assert _psd_err(got.cpu().numpy(), want) <= 1.0
 
 
+def test_welch_full_size_against_torch_fft():
+    """Welch at the bench's launch size (16384 epochs x 30 channels x 1500 samples): every row against a float64
+    torch.fft restatement of the same definition on the GPU (segments, mean removal, periodic Hann, one-sided density),
+    plus homogeneity psd(a x) = a^2 psd(x) bit-for-bit for a power-of-two a."""
+    E, C, T, fs, nfft, hop = 16384, 30, 1500, 500.0, 500, 250
+    x = synth_epochs(E, C, T, seed=17, device=DEV, chunk=2048) + 2e-5
+    psd, freqs = lbm_amd.psd_array_welch(x, fs, 4.0, 30.0, n_fft=nfft, n_overlap=nfft - hop, window="hann")
+    assert psd.shape == (E, C, 27)
+    n = torch.arange(nfft, device=DEV, dtype=torch.float64)
+    w = 0.5 - 0.5 * torch.cos(2.0 * math.pi * n / nfft)
+    scale = 2.0 / (fs * float((w * w).sum()))
+    worst = 0.0
+    for lo in range(0, E, 1024):
+        seg = x[lo:lo + 1024].double().unfold(-1, nfft, hop)            # [e, c, 5, 500]
+        seg = (seg - seg.mean(-1, keepdim=True)) * w
+        p = (torch.fft.rfft(seg, dim=-1)[..., 4:31].abs() ** 2).mean(-2) * scale
+        got = psd[lo:lo + 1024].double()
+        tol = 1e-5 * p + 1e-5 * p.max(dim=-1, keepdim=True).values
+        worst = max(worst, float(((got - p).abs() / tol).max()))
+    assert worst <= 1.0
+    psd4, _ = lbm_amd.psd_array_welch(x[:2048] * 4.0, fs, 4.0, 30.0, n_fft=nfft, n_overlap=nfft - hop, window="hann")
+    assert torch.equal(psd4, psd[:2048] * 16.0)
+
+
 # ------------------------------------------------------------------------------------------------ a8 / a9
 def test_bandpower_known_answer_labels(golden_dir):
     with np.load(os.path.join(golden_dir, "bandpower_kat.npz")) as f:
