@@ -694,6 +694,35 @@ def test_pipeline_full_size_properties(shipped):
     assert bool(torch.isfinite(o1["psd"]).all()) and bool((o1["psd"] > 0).all())
 
 
+def test_encoder_and_affine_large_batch_against_torch_float64(shipped):
+    """The conv stack and the channel affine map on a 4096-epoch batch (every position tile shape and tile edge many
+    times over) against float64 torch on the GPU."""
+    from lbm_amd.quantizer import encoder_forward
+    E = 4096
+    x = synth_epochs(E, 30, 1500, seed=19, device=DEV, chunk=2048) * 1e5      # ~unit scale, as after the z-score
+    w = {k: torch.from_numpy(v).to(DEV) for k, v in shipped.items() if k.startswith("encoder.")}
+    z = encoder_forward(x, w)
+    assert z.shape == (E, 256, 375)
+    F_ = torch.nn.functional
+    worst = 0.0
+    for lo in range(0, E, 512):
+        h = x[lo:lo + 512].double()
+        h = F_.relu(F_.conv1d(h, w["encoder.0.weight"].double(), w["encoder.0.bias"].double(), stride=2, padding=1))
+        h = F_.relu(F_.conv1d(h, w["encoder.2.weight"].double(), w["encoder.2.bias"].double(), stride=2, padding=1))
+        h = F_.relu(F_.conv1d(h, w["encoder.4.weight"].double(), w["encoder.4.bias"].double(), stride=1, padding=1))
+        h = F_.conv1d(h, w["encoder.6.weight"].double(), w["encoder.6.bias"].double())
+        worst = max(worst, float((z[lo:lo + 512].double() - h).abs().max() / h.abs().max()))
+    assert worst <= 2e-5
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    At, bt = torch.as_tensor(A).to(DEV), torch.as_tensor(b).to(DEV)
+    y = lbm_amd.affine_channels(x, At.float(), bt.float())
+    werr = 0.0
+    for lo in range(0, E, 1024):
+        ref = torch.einsum("oc,ect->eot", At.double(), x[lo:lo + 1024].double()) + bt.double()[None, :, None]
+        werr = max(werr, float((y[lo:lo + 1024].double() - ref).abs().max() / ref.abs().max()))
+    assert werr <= 1e-6
+
+
 def test_vq_full_size_every_row_is_a_minimum(shipped):
     """The quantizer at the bench's launch size (16384 x 375 rows, channel-major, K = 512: the LDS-DMA kernel): every
     returned code attains the row's minimum distance within the near-tie band, recomputed with torch on the GPU;
