@@ -723,6 +723,40 @@ def test_encoder_and_affine_large_batch_against_torch_float64(shipped):
     assert werr <= 1e-6
 
 
+def test_fir_and_post_large_batch_against_torch_float64():
+    """FIR fast convolution and the epoch post-processing on a 4096-epoch batch against float64 torch on the GPU
+    (odd-reflection padding + FFT convolution; baseline, peak-to-peak mask, z-score)."""
+    E, C, T = 4096, 30, 1500
+    x = synth_epochs(E, C, T, seed=23, device=DEV, chunk=2048)
+    burst = 2e-4 * torch.sin(2.0 * math.pi * 10.0 * torch.arange(T, device=DEV) / 500.0)   # in-band artefacts -> rejected epochs
+    x[17, 3] += burst
+    x[4000, 29] -= burst
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    y = lbm_amd.filter_data(x, 500.0, 4.0, 30.0)
+    h = torch.as_tensor(np.asarray(taps, dtype=np.float64)).to(DEV)
+    half = (h.numel() - 1) // 2
+    N = 4096
+    H = torch.fft.rfft(h, n=N)
+    worst = 0.0
+    for lo in range(0, E, 512):
+        xr = x[lo:lo + 512].double().reshape(-1, T)
+        left = 2.0 * xr[:, :1] - xr[:, 1:half + 1].flip(-1)
+        right = 2.0 * xr[:, -1:] - xr[:, -half - 1:-1].flip(-1)
+        xp = torch.cat([left, xr, right], dim=-1)                                  # T + 2 half
+        full = torch.fft.irfft(torch.fft.rfft(xp, n=N) * H, n=N)                   # linear convolution (T + 2 half + 2 half < N)
+        ref = full[:, 2 * half:2 * half + T]
+        worst = max(worst, float((y[lo:lo + 512].double().reshape(-1, T) - ref).abs().max() / ref.abs().max()))
+    assert worst <= 2e-5
+    base, std, keep = lbm_amd.epoch_post(y, n_baseline=251, reject=150e-6, standardize=True)
+    yd = y.double()
+    bref = yd - yd[..., :251].mean(-1, keepdim=True)
+    kref = ((yd.max(-1).values - yd.min(-1).values) <= 150e-6).all(-1)
+    sref = (bref - bref.mean(-1, keepdim=True)) / (bref.std(-1, unbiased=False, keepdim=True) + 1e-6)
+    assert torch.equal(keep, kref) and int((~kref).sum()) >= 2
+    assert float((base.double() - bref).abs().max()) <= 1e-5 * float(bref.abs().max())
+    assert float((std.double() - sref).abs().max()) <= 2e-5 * float(sref.abs().max())
+
+
 def test_vq_full_size_every_row_is_a_minimum(shipped):
     """The quantizer at the bench's launch size (16384 x 375 rows, channel-major, K = 512: the LDS-DMA kernel): every
     returned code attains the row's minimum distance within the near-tie band, recomputed with torch on the GPU;
