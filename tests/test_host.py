@@ -108,3 +108,15 @@ def test_argument_validation_without_launch():
     assert lib.lbm_welch_f32(None, None, None, 10, 100, 500.0, 500, 500, 250, None, 4, 30, 0, None) == -1  # nfft > T
     assert b"larger than the number of samples" in lib.lbm_last_error()
     assert lib.lbm_welch_tables_bytes(500, 500, 4, 30) >= 64 + 4 * 1500
+    # the bf16-piece entry points and the resampler
+    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 and lib.lbm_vq_split_tables_bytes(512, 300) == 0
+    assert lib.lbm_conv1d_split_tables_bytes(128, 256, 3) == 24 * 3 * 256 * 32
+    assert lib.lbm_conv1d_split_tables_bytes(30, 64, 4) == 8 * 3 * 256 * 32            # Cin -> 32, Cout -> 256
+    assert lib.lbm_conv1d_split_tables_bytes(5000, 64, 4) == 0
+    assert lib.lbm_vq_argmin_bf16x6_f32(None, 256, 0, 0, None, None, None, None, None, 10, 300, 512, None) == -2
+    assert lib.lbm_vq_argmin_bf16x6_f32(None, 256, 0, 0, None, None, None, None, None, 10, 256, 512, None) == -1
+    assert b"NULL" in lib.lbm_last_error()
+    assert lib.lbm_conv1d_bf16x6_f32(None, 376, None, None, None, 376, 4, 128, 375, 256, 3, 1, 1, 1, None) == -1
+    assert lib.lbm_conv1d_bf16x6_f32(None, 376, None, None, None, 376, 0, 128, 375, 256, 3, 1, 1, 1, None) == 0   # empty batch
+    assert lib.lbm_resample_length(1800000, 250, 500) == 900000 and lib.lbm_resample_length(1000, 3, 7) == 0
+    assert lib.lbm_resample_fft_f32(None, 1000, None, 500, 2, 1000, 3, 7, None, None) < 0
