@@ -8,9 +8,13 @@ Welch PSD -> band powers -> VQ-VAE encoder -> codebook argmin + usage histogram)
 config 3: 1 000 000 synthetic 30-channel x 500 Hz x 3 s fp32 epochs per GPU, RESIDENT in HBM (180 GB) before
 the timed region, walked in chunks of 16 384 epochs (the pipeline's stage buffers are sized for one chunk).
 Per-epoch outputs (tokens, PSD, band features, keep mask) are kept for the whole job.
-For N > 1 (torchrun, one rank per GPU) every rank processes its own 1 M epochs (weak scaling: config 4, epochs
-shard trivially); the only collectives of the path -- all-gather of the token array and all-reduce of the
-codebook usage histogram -- run once per step inside the timed region.
+For N > 1 every rank (one process per GPU) processes its own 1 M epochs (weak scaling: config 4, epochs shard
+trivially).  The only collectives of the path run inside the timed region: all-gather of the token, PSD,
+band-feature and keep-mask arrays -- issued per group of chunks on RCCL's own stream while the next group
+computes -- and one all-reduce of the codebook usage histogram per step.
+Ranks: under torchrun (RANK / WORLD_SIZE set) this process IS one rank; otherwise `--gpus N` with N > 1 makes this
+process a launcher that starts N fresh rank processes itself (it never touches the GPU), relays rank 0's JSON line
+and fails if any rank fails.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -25,8 +29,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import lbm_amd  # noqa: E402
-from lbm_amd.synth import synth_codebook, synth_epochs, synth_ica  # noqa: E402
+lbm_amd = synth_codebook = synth_epochs = synth_ica = None    # bound by _import_product() in a rank process
+
+
+def _import_product():
+    """Import the package (and with it the ctypes binding) in a RANK process only: the launcher parent stays free of
+    anything that could initialise the GPU."""
+    global lbm_amd, synth_codebook, synth_epochs, synth_ica
+    import lbm_amd as _pkg
+    from lbm_amd.synth import synth_codebook as _cb, synth_epochs as _ep, synth_ica as _ica
+    lbm_amd, synth_codebook, synth_epochs, synth_ica = _pkg, _cb, _ep, _ica
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -35,14 +47,16 @@ KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine": "affine_kernel", "post": "
                    "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1,1,256>", "vq": "vq_argmin_dma_kernel"}
 
 
-def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048):
+def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False):
     """Algorithmic flops / compulsory HBM bytes per launch of each stage over E epochs (SURVEY.md 8d figures)."""
     ep = C * T * 4
     fft_flops = 2 * 5.0 * fft_n * np.log2(fft_n) + 6.0 * fft_n       # forward + inverse complex FFT + spectrum product, per row
     return {
         "fir": dict(flops=fft_flops * C * E, direct_flops=2.0 * ntaps * C * T * E, bytes=2.0 * ep * E, bound="hbm"),
         "affine": dict(flops=2.0 * C * C * T * E, bytes=2.0 * ep * E, bound="hbm"),
-        "post": dict(flops=8.0 * C * T * E, bytes=3.0 * ep * E, bound="hbm"),
+        "post": dict(flops=8.0 * C * T * E, bytes=(3.0 if emit_cleaned else 2.0) * ep * E, bound="hbm"),
+        # fused ICA affine + baseline / peak-to-peak / z-score: one read, one write (two with the cleaned epochs)
+        "affine_post": dict(flops=(2.0 * C * C + 8.0 * C) * T * E, bytes=(3.0 if emit_cleaned else 2.0) * ep * E, bound="hbm"),
         "welch": dict(flops=2.0e6 * E * (C * T / 45000.0), bytes=(ep + C * F * 4) * E, bound="hbm"),
         "bandpower": dict(flops=0.0, bytes=(C * F * 4 + 24) * E, bound="hbm"),
         "conv1": dict(flops=2.0 * 64 * C * 4 * L1 * E, bytes=(ep + 64 * L1 * 4) * E, bound="mfma"),
@@ -53,11 +67,120 @@ def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048):
     }
 
 
+def stage_report(acc, model):
+    """name -> ms / achieved rate / fraction of the bounding peak (HBM 8 TB/s for the DSP stages: north_star asks >= 0.60 there)."""
+    stages = {}
+    for name, ms in acc.items():
+        m = float(np.mean(ms))
+        mod = model[name]
+        tf = mod["flops"] / (m * 1e-3) / 1e12
+        gb = mod["bytes"] / (m * 1e-3) / 1e9
+        stages[name] = {"ms": round(m, 4), "bound": mod["bound"], "tflops": round(tf, 3), "gbs": round(gb, 1),
+                        "frac": round(tf / PEAK_FP32_TFLOPS if mod["bound"] == "mfma" else gb / PEAK_HBM_GBS, 4)}
+    return stages
+
+
+def _timed_chunks(pipe, x, n_epochs, chunk, reps=2):
+    """ms for n_epochs walked in chunks over the (smaller) resident buffer x, HIP events on the launch stream."""
+    R = x.shape[0]
+
+    def walk():
+        pipe.reset_hist()
+        for lo in range(0, n_epochs, chunk):
+            n = min(chunk, n_epochs - lo)
+            src = lo % R
+            if src + n > R:
+                src = R - n
+            pipe.run(x[src:src + n])
+    walk()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        walk()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def extra_configs(dev, taps, A, b, weights):
+    """BASELINE.json configs 1, 2 and 5, measured in the same process OUTSIDE the timed region (reported, never `value`)."""
+    from oracle import eeg_oracle as orc          # checker + CPU leg only (config 1 IS the CPU reference path)
+    out = {}
+    cb = weights["vq_layer.embedding.weight"]
+    # ---- config 1: the reference's own shapes (30 x 1001 @ 500 Hz, 313 epochs = len(s02_051115m_labels.npy)); the subject's
+    # epochs blob is not shipped (.MISSING_LARGE_BLOBS), so synthetic epochs of that shape: CPU oracle rate + parity matrix
+    E1, T1 = 313, 1001
+    x1 = synth_epochs(E1, 30, T1, seed=313) * 2.0
+    cfg1 = lbm_amd.PipelineConfig(sfreq=500.0, n_channels=30, n_times=T1, n_baseline=251, emit_cleaned=True)
+    p1 = lbm_amd.EpochPipeline(cfg1, taps, A, b, weights, cb, device=dev)
+    x1d = x1.to(dev)
+    got = {k: v.cpu().numpy() for k, v in p1.run(x1d).items()}
+    ms1 = _timed_chunks(p1, x1d, E1, E1, reps=5)
+    t0 = time.perf_counter()
+    want = orc.pipeline(x1.numpy(), 500.0, taps, A, b, 251, 150e-6, weights, fft_filter=True)
+    cpu_s = time.perf_counter() - t0
+    rms = lambda a, w: float((np.abs(a - w) / (np.sqrt((w ** 2).mean(axis=-1, keepdims=True)) + 1e-300)).max())  # noqa: E731
+    psd_err = float((np.abs(got["psd"] - want["psd"]) / (1e-5 * want["psd"].max(axis=-1, keepdims=True) + 1e-5 * np.abs(want["psd"]))).max())
+    out["config1"] = {
+        "workload": "313 synthetic epochs of the reference's shape (30ch x 1001 samples @ 500 Hz): full pipeline, GPU vs CPU oracle",
+        "gpu_epochs_per_s": round(E1 / (ms1 * 1e-3), 1), "cpu_oracle_epochs_per_s": round(E1 / cpu_s, 1),
+        "parity": {"cleaned_max_err_over_row_rms": rms(got["cleaned"], want["filtered"]),
+                   "standardized_max_abs_err": float(np.abs(got["standardized"] - want["standardized"]).max()),
+                   "psd_max_err_in_units_of_tol(rtol1e-5+atol1e-5*rowmax)": psd_err,
+                   "bandpower_max_rel_err": float(np.abs(got["bandpower"] / want["bandpower"] - 1).max()),
+                   "keep_mask_equal": bool(np.array_equal(got["keep"].astype(bool), want["keep"])),
+                   "token_agreement": float((got["tokens"] == want["tokens"]).mean()),
+                   "token_mismatches_all_documented_near_ties": bool(orc.vq_near_tie_ok(
+                       np.transpose(got["z"], (0, 2, 1)).reshape(-1, 256), cb, got["tokens"].reshape(-1),
+                       orc.vq_argmin(np.transpose(got["z"], (0, 2, 1)).reshape(-1, 256), cb)).all())}}
+    del p1, x1d
+    # ---- config 2: PSD + band-power features only, 100 000 S-shape epochs (do_tokenize=False, no filter / ICA): HBM-bound
+    E2, ch2 = 100_000, 16384
+    cfg2 = lbm_amd.PipelineConfig(sfreq=500.0, n_channels=30, n_times=1500, n_baseline=251, do_tokenize=False, do_filter=False,
+                                  do_ica=False, emit_cleaned=False)
+    p2 = lbm_amd.EpochPipeline(cfg2, None, None, None, None, None, device=dev)
+    x2 = synth_epochs(ch2, 30, 1500, seed=2, device=dev, chunk=2048)
+    p2.stage_events = []
+    ms2 = _timed_chunks(p2, x2, E2, ch2, reps=3)
+    acc = {}
+    for name, s_, e_ in p2.stage_events:
+        acc.setdefault(name, []).append(s_.elapsed_time(e_))
+    p2.stage_events = None
+    by = 183_264.0 * E2
+    out["config2"] = {"workload": "100 000 synthetic 30x1500 epochs, Welch PSD + band power only (reject mask included), 1 GPU",
+                      "epochs_per_s": round(E2 / (ms2 * 1e-3), 1), "ms": round(ms2, 3),
+                      "algorithmic_bytes_per_epoch": 183_264, "gbs": round(by / (ms2 * 1e-3) / 1e9, 1),
+                      "hbm_frac": round(by / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                      "stage_ms_per_chunk": {k: round(float(np.mean(v)), 4) for k, v in acc.items()}}
+    del p2, x2
+    torch.cuda.empty_cache()
+    # ---- config 5: 64ch x 1 kHz x 10 s epochs, K = 8192 codebook, 16 384 epochs per GPU, walked in chunks of 1024
+    from lbm_amd.synth import synth_encoder
+    C5, T5, fs5, K5, E5, ch5 = 64, 10000, 1000.0, 8192, 16384, 1024
+    taps5 = lbm_amd.create_filter(fs5, 4.0, 30.0)
+    A5, b5 = lbm_amd.ica_projection(**synth_ica(C5))
+    cfg5 = lbm_amd.PipelineConfig(sfreq=fs5, n_channels=C5, n_times=T5, n_baseline=501, emit_cleaned=False)
+    p5 = lbm_amd.EpochPipeline(cfg5, taps5, A5, b5, synth_encoder(C5), synth_codebook(K5, 256), device=dev)
+    x5 = synth_epochs(ch5, C5, T5, sfreq=fs5, seed=5, device=dev, chunk=128)
+    p5.stage_events = []
+    ms5 = _timed_chunks(p5, x5, E5, ch5, reps=1)
+    acc = {}
+    for name, s_, e_ in p5.stage_events:
+        acc.setdefault(name, []).append(s_.elapsed_time(e_))
+    p5.stage_events = None
+    m5 = stage_model(ch5, C5, T5, len(taps5), K5, 256, p5.S, p5.L1, p5.F, 3 * 4096)
+    out["config5"] = {"workload": "16 384 synthetic 64ch x 1 kHz x 10 s epochs, K=8192 codebook, full pipeline, chunks of 1024 "
+                                  "(one resident 1024-epoch buffer re-walked)",
+                      "epochs_per_s": round(E5 / (ms5 * 1e-3), 1), "ms": round(ms5, 2), "stages": stage_report(acc, m5)}
+    return out
+
+
 def cpu_baseline(taps, A, b, weights, sample_epochs):
     """Times the CPU oracle (float64 SciPy DSP + torch-CPU fp32 encoder/quantizer) on a bounded sample."""
     from oracle import eeg_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, 16))           # a 1-GPU box's CPU share is 16 threads, whatever the machine has
     torch.set_num_threads(cores)
     x = synth_epochs(sample_epochs, 30, 1500, seed=99).numpy()
     t0 = time.perf_counter()
@@ -81,7 +204,8 @@ def cpu_baseline(taps, A, b, weights, sample_epochs):
     h = timed("encoder", lambda: orc.encoder_forward(std.astype(np.float32), weights))
     flat = np.ascontiguousarray(np.transpose(np.asarray(h), (0, 2, 1))).reshape(-1, np.asarray(h).shape[1])
     timed("vq", lambda: orc.vq_argmin(flat, weights["vq_layer.embedding.weight"]))
-    return {"value": round(sample_epochs / dt, 1), "unit": "epochs/s", "cores": cores, "kind": "port",
+    return {"value": round(sample_epochs / dt, 1), "unit": "epochs/s", "cores": cores, "host_cpus_visible": avail,
+            "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{sample_epochs} synthetic 30x1500 epochs through oracle/eeg_oracle.pipeline "
                       f"(float64 scipy FIR(oaconvolve)/ICA/Welch + torch-CPU fp32 encoder+VQ), {dt:.1f} s",
             "stage_epochs_per_s": per}
@@ -96,9 +220,9 @@ def alloc_resident(E, C, T, dev, reserve_bytes):
     return torch.empty((R, C, T), dtype=torch.float32, device=dev)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; N > 1 without torchrun: this process launches them")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--epochs", type=int, default=1_000_000, help="epochs per step per GPU (BASELINE config 3: 1M)")
@@ -106,6 +230,10 @@ def main():
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-groups", type=int, default=16,
+                    help="N > 1: the per-epoch outputs are all-gathered in this many groups of chunks, each group's exchange "
+                         "running on the collective stream while the next group computes (1 = one exchange at the end of the step)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the out-of-timed-region measurements of BASELINE configs 1, 2, 5")
     ap.add_argument("--from-host", action="store_true",
                     help="non-default: every chunk arrives from pinned host memory (PCIe-inclusive rate; H2D copies of chunk i+1 "
                          "on a copy stream overlap the kernels of chunk i)")
@@ -124,7 +252,7 @@ def main():
     ap.add_argument("--shape", choices=["S", "L"], default="S",
                     help="S = 30ch x 500Hz x 3s, K=512 (configs 3/4, the metric's workload); L = 64ch x 1kHz x 10s, "
                          "K=8192, 16384 epochs (config 5, for measurement only)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.shape == "L":
         if args.epochs == 1_000_000:
             args.epochs = 16384
@@ -132,7 +260,134 @@ def main():
             args.codebook = 8192
         args.chunk = min(args.chunk, 1024)
         args.cpu_sample = 0
+    return args
 
+
+# ---------------------------------------------------------------------------------------------- launcher (no GPU call here)
+def rank_env(base_env, rank, world, port):
+    """Environment of rank `rank` of a `world`-rank single-node job (what torchrun would set)."""
+    env = dict(base_env)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+    return env
+
+
+def launch_ranks(world, argv, script=None, popen=None):
+    """Start `world` fresh rank processes of this script (same argv), wait for them, print rank 0's JSON line.
+    Returns the exit code: 0 only if every rank exited 0.  The parent has made no GPU call and never re-execs."""
+    import socket
+    import subprocess
+    popen = popen or subprocess.Popen
+    script = script or os.path.abspath(__file__)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    rc = 0
+    with tempfile.TemporaryFile(mode="w+") as out0_file:
+        try:
+            for r in range(world):
+                procs.append(popen([sys.executable, "-u", script, *argv], env=rank_env(os.environ, r, world, port),
+                                   stdout=out0_file if r == 0 else sys.stderr))
+            live = set(range(world))
+            while live:
+                for r in sorted(live):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    live.discard(r)
+                    if code != 0:                        # one rank down: the others would wait in a collective until it times out
+                        rc = rc or (code if code > 0 else 1)
+                        print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                        for q in live:
+                            procs[q].kill()              # exactly the children started above, by handle
+                if live:
+                    time.sleep(0.1)
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                pr.wait()
+        out0_file.seek(0)
+        out0 = out0_file.read()
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            print(ln, file=sys.stderr)
+    if rc == 0 and not js:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    if js:
+        print(js[-1])
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, argv))
+    world = int(env_world or "1")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself; under torchrun pass --gpus = --nproc-per-node)")
+    run_rank(args)
+
+
+# ---------------------------------------------------------------------------------------------- exchange step (N > 1)
+class Exchange:
+    """all-gather of the per-epoch output arrays in rank order (np.concatenate order, training/model.py:423), group by group.
+
+    nccl: per group and array one `all_gather` into the [world, E, ...] result's contiguous [w, lo:hi] slices with
+    async_op=True: RCCL's stream waits for the compute enqueued so far and the exchange then overlaps the next group's kernels.
+    gloo (rehearsal only): the same calls on host copies."""
+
+    def __init__(self, dist, backend, world, arrays, dev):
+        self.dist, self.backend, self.world = dist, backend, world
+        self.local = arrays                                                   # name -> [E, ...] local tensor
+        self.wire = {k: (v.view(torch.uint8) if v.dtype == torch.int16 else v) for k, v in arrays.items()}   # RCCL has no int16: bytes
+        self.out = {k: torch.empty((world,) + tuple(v.shape), dtype=v.dtype, device=dev) for k, v in self.wire.items()}
+        self.pending = []
+
+    def bytes_per_epoch(self):
+        return sum(v[0].numel() * v.element_size() for v in self.wire.values())
+
+    def gather_group(self, lo, hi):
+        for k, v in self.wire.items():
+            if self.backend == "nccl":
+                self.pending.append(self.dist.all_gather([self.out[k][w, lo:hi] for w in range(self.world)], v[lo:hi], async_op=True))
+            else:
+                h = [torch.empty(v[lo:hi].shape, dtype=v.dtype) for _ in range(self.world)]
+                self.dist.all_gather(h, v[lo:hi].cpu())
+                for w in range(self.world):
+                    self.out[k][w, lo:hi].copy_(h[w])
+
+    def finish(self, hist):
+        for wk in self.pending:
+            wk.wait()                                                         # current stream waits for RCCL's stream
+        self.pending = []
+        if self.backend == "nccl":
+            self.dist.all_reduce(hist)
+        else:
+            hh = hist.cpu()
+            self.dist.all_reduce(hh)
+            hist.copy_(hh)
+
+    def gathered(self, name):
+        """[world * E, ...] view in rank order, at the API dtype of the local array."""
+        o = self.out[name]
+        loc = self.local[name]
+        if loc.dtype == torch.int16:
+            o = o.view(torch.int16)
+        return o.reshape((-1,) + tuple(loc.shape[1:]))
+
+
+def run_rank(args):
+    _import_product()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -160,7 +415,8 @@ def main():
         from lbm_amd.synth import synth_encoder
         weights = synth_encoder(C)
     codebook = weights["vq_layer.embedding.weight"] if (K == 512 and args.shape == "S") else synth_codebook(K, D)
-    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1,
+    nb = int(round(0.5 * fs)) + 1
+    cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb,
                                  fold_projection=args.fold_proj, vq_method=args.vq, conv_method=args.conv,
                                  emit_cleaned=args.emit_cleaned)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
@@ -173,8 +429,17 @@ def main():
     psd = torch.empty((E, C, F), dtype=torch.float32, device=dev)
     bp = torch.empty((E, 6), dtype=torch.float32, device=dev)
     keep = torch.empty((E,), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((world * E, S), dtype=tok_dtype, device=dev) if (world > 1 and not args.no_gather) else None
-    x = alloc_resident(E, C, T, dev, reserve_bytes=6 << 30)
+    xch = None
+    nchunks = (E + chunk - 1) // chunk
+    groups = max(1, min(args.gather_groups, nchunks))
+    if world > 1 and not args.no_gather:
+        xch = Exchange(dist, args.backend, world, {"tokens": tokens, "psd": psd, "bandpower": bp, "keep": keep}, dev)
+    # room left beside the resident input: allocator slack, RCCL's buffers and (N > 1) the flattened receive buffers torch
+    # stages one group of each array through before it scatters them to the [w, lo:hi] slices
+    reserve = 6 << 30
+    if xch is not None:
+        reserve += (2 << 30) + 3 * world * ((E + groups - 1) // groups) * xch.bytes_per_epoch()
+    x = alloc_resident(E, C, T, dev, reserve_bytes=reserve)
     R = x.shape[0]
     synth_epochs(R, C, T, sfreq=fs, seed=lbm_amd.synth.SEED + rank, device=dev, chunk=2048, out=x)
     torch.cuda.synchronize()
@@ -185,9 +450,14 @@ def main():
         host_ring = [x[:chunk].cpu().pin_memory() for _ in range(2)]
         dev_ring = [torch.empty((chunk, C, T), dtype=torch.float32, device=dev) for _ in range(2)]
 
+    def store(lo, n, out):
+        tokens[lo:lo + n].copy_(out["tokens"])
+        psd[lo:lo + n].copy_(out["psd"])
+        bp[lo:lo + n].copy_(out["bandpower"])
+        keep[lo:lo + n].copy_(out["keep"])
+
     def step_from_host():
         pipe.reset_hist()
-        nchunks = (E + chunk - 1) // chunk
         ready = [torch.cuda.Event() for _ in range(2)]
         freed = [torch.cuda.Event() for _ in range(2)]
         with torch.cuda.stream(copy_stream):
@@ -206,37 +476,30 @@ def main():
             n = min(chunk, E - lo)
             out = pipe.run(dev_ring[cur][:n])
             freed[cur].record()
-            tokens[lo:lo + n].copy_(out["tokens"])
-            psd[lo:lo + n].copy_(out["psd"])
-            bp[lo:lo + n].copy_(out["bandpower"])
-            keep[lo:lo + n].copy_(out["keep"])
+            store(lo, n, out)
         return pipe._buf["hist"]
+
+    # chunk index at which each exchange group ends (groups of whole chunks, as equal as they come)
+    group_end = {((g + 1) * nchunks) // groups - 1: g for g in range(groups)}
 
     def step():
         if args.from_host:
             return step_from_host()
         pipe.reset_hist()
-        for lo in range(0, E, chunk):
+        g_lo = 0
+        for i in range(nchunks):
+            lo = i * chunk
             n = min(chunk, E - lo)
             src = lo % R
             if src + n > R:
                 src = R - n
-            out = pipe.run(x[src:src + n])
-            tokens[lo:lo + n].copy_(out["tokens"])
-            psd[lo:lo + n].copy_(out["psd"])
-            bp[lo:lo + n].copy_(out["bandpower"])
-            keep[lo:lo + n].copy_(out["keep"])
+            store(lo, n, pipe.run(x[src:src + n]))
+            if xch is not None and i in group_end:
+                xch.gather_group(g_lo, lo + n)        # this group's exchange rides under the next group's kernels
+                g_lo = lo + n
         hist = pipe._buf["hist"]
-        if gathered is not None and args.backend == "nccl":
-            dist.all_gather_into_tensor(gathered.view(torch.uint8), tokens.view(torch.uint8))   # RCCL has no int16: bytes
-            dist.all_reduce(hist)
-        elif gathered is not None:                      # gloo rehearsal: same calls on host copies
-            g_host = torch.empty(gathered.shape, dtype=gathered.dtype).view(torch.uint8)
-            dist.all_gather_into_tensor(g_host, tokens.cpu().view(torch.uint8))
-            gathered.view(torch.uint8).copy_(g_host)
-            h_host = hist.cpu()
-            dist.all_reduce(h_host)
-            hist.copy_(h_host)
+        if xch is not None:
+            xch.finish(hist)
         return hist
 
     for _ in range(args.warmup):
@@ -258,21 +521,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # the exchange step alone ("report gather time separately"), outside the timed region
+    # the exchange step alone, NOT overlapped ("report gather time separately"), outside the timed region
     gather_ms = None
-    if gathered is not None and args.backend == "nccl":
+    gather_ok = None
+    if xch is not None:
         torch.cuda.synchronize()
         dist.barrier()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), tokens.view(torch.uint8))
-        dist.all_reduce(pipe._buf["hist"])
+        xch.gather_group(0, E)
+        xch.finish(pipe._buf["hist"])
         g1.record()
         torch.cuda.synchronize()
         gather_ms = round(g0.elapsed_time(g1), 3)
+        # order check: this rank's block of every gathered array is its own local array
+        gather_ok = all(bool(torch.equal(xch.gathered(k)[rank * E:(rank + 1) * E], v)) for k, v in xch.local.items())
 
     # per-kernel durations from HIP events recorded on the launch stream (one chunk, outside the timed region)
     stages = {}
+    model = {}
     if rank == 0:
         reps = 5
         pipe.stage_events = []
@@ -285,24 +552,19 @@ def main():
             acc.setdefault(name, []).append(s_.elapsed_time(e_))
         pipe.stage_events = None
         fft_n = 2048 if args.shape == "S" else 3 * 4096
-        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n)
-        if not args.emit_cleaned:
-            model["post"]["bytes"] = 2.0 * C * T * 4 * chunk      # one read, one write (standardized)
-        for name, ms in acc.items():
-            m = float(np.mean(ms))
-            stages[name] = {"ms": round(m, 4), "bound": model[name]["bound"],
-                            "tflops": round(model[name]["flops"] / (m * 1e-3) / 1e12, 3),
-                            "gbs": round(model[name]["bytes"] / (m * 1e-3) / 1e9, 1)}
+        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned)
+        stages = stage_report(acc, model)
 
     # non-default variants of the tokenizer tail, same chunk, outside the timed region (reported, never `value`)
     variants = {}
     if rank == 0 and args.shape == "S" and not args.fold_proj and args.vq == "fp32" and args.conv == "fp32":
         base_ms = sum(v["ms"] for v in stages.values())
-        for name, kw in (("vq_bf16x6", dict(vq_method="bf16x6")),
+        for name, kw in (("fp32+fold_projection", dict(fold_projection=True)),
+                         ("vq_bf16x6", dict(vq_method="bf16x6")),
                          ("vq_bf16x6+conv_bf16x6", dict(vq_method="bf16x6", conv_method="bf16x6")),
                          ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True)),
                          ("vq_bf16x6+conv_bf16x6+fold_projection", dict(vq_method="bf16x6", conv_method="bf16x6", fold_projection=True))):
-            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=int(round(0.5 * fs)) + 1, emit_cleaned=args.emit_cleaned, **kw)
+            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, **kw)
             vp = lbm_amd.EpochPipeline(vcfg, taps, A, b, weights, codebook, device=dev)
             vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z is unused when folded)
             vp.run(x[:chunk])
@@ -325,16 +587,24 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
         m = model[dom]
-        if m["bound"] == "mfma":
-            roof = {"kernel": KERNEL_OF_STAGE[dom], "bound": "mfma", "achieved": stages[dom]["tflops"], "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(stages[dom]["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": traffic}
-        else:
-            roof = {"kernel": KERNEL_OF_STAGE[dom], "bound": "hbm", "achieved": stages[dom]["gbs"], "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(stages[dom]["gbs"] / PEAK_HBM_GBS, 4), "traffic": traffic}
-        roof["launch"] = f"{chunk} epochs, {stages[dom]['ms']} ms"
+        key, peak, unit = ("tflops", PEAK_FP32_TFLOPS, "TFLOP/s") if m["bound"] == "mfma" else ("gbs", PEAK_HBM_GBS, "GB/s")
+        roof = {"kernel": KERNEL_OF_STAGE.get(dom, dom), "bound": m["bound"], "achieved": stages[dom][key], "peak": peak, "unit": unit,
+                "frac": round(stages[dom][key] / peak, 4), "traffic": traffic,
+                "traffic_source": "stored counter run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, "
+                                  "profiles/pmc_traffic.json), not measured in this process" if traffic is not None else None,
+                "launch": f"{chunk} epochs, {stages[dom]['ms']} ms"}
         cpu = None
+        extras = {}
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(taps, A, b, weights, args.cpu_sample)
+        if world == 1 and args.shape == "S" and not args.no_extras:
+            del x                                        # the extras bring their own (small) inputs
+            torch.cuda.empty_cache()
+            extras = extra_configs(dev, taps, A, b, weights)
+        coll = "none"
+        if xch is not None:
+            coll = ("all_gather(tokens int16 + PSD f32 + band features f32 + keep u8; %d groups, async on the collective stream)"
+                    "+all_reduce(hist)" % groups)
         line = {
             "metric": "EEG epochs/sec (filter+ICA+PSD+VQ tokenize)",
             "value": round(world * E * args.steps / dt, 1),
@@ -350,14 +620,18 @@ def main():
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
                        "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
-                       "collectives": "all_gather(tokens,int16)+all_reduce(hist)" if gathered is not None else "none"},
+                       "collectives": coll, "backend": args.backend if world > 1 else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "stages": stages,
             "gather_ms_per_step": gather_ms,
+            "gather_bytes_per_rank": (xch.bytes_per_epoch() * E) if xch is not None else None,
+            "gather_order_ok": gather_ok,
             "variants": variants,
+            "other_configs": extras,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()   # rank 0 measured the per-stage events and variants alone: leave together
         dist.destroy_process_group()

@@ -92,15 +92,22 @@ def check(rc: int, what: str = ""):
 
 
 def stream_ptr() -> int:
+    """The current stream of the CURRENT device: launches go to the current HIP device, so every tensor handed to a call
+    must live there (``ptr`` checks it)."""
     return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
+    """Device pointer of a tensor (None -> NULL).  Raises for CPU tensors and for tensors of another GPU than the current
+    one: a kernel launched on device A's stream against device B's pointers faults or silently goes through peer access --
+    wrap the call in ``with torch.cuda.device(t.device):`` instead."""
     if t is None:
         return None
     if not t.is_cuda:
         raise LbmError("lbm_amd kernels need CUDA/ROCm tensors (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        raise LbmError(f"tensor lives on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()}: "
+                       "run the call under `with torch.cuda.device(tensor.device)`")
     return t.data_ptr()
 
 

@@ -22,10 +22,11 @@ Plan make_plan(int64_t T, int up, int down) {
     p.T = T;
     if (T < 1 || up < 1 || down < 1) return p;
     // (llrint: round-half-even, as Python's round() in MNE's length arithmetic)
-    // MNE npad='auto': min_add = min(T // 8, 100) * 2; N = 2^ceil(log2(T + 2 * min_add))
+    // MNE npad='auto' (mne/filter.py resample): min_add = min(x_len // 8, 100) * 2; npad = 2^ceil(log2(x_len + min_add)) - x_len
+    // (the doubling is already inside min_add; round 1 doubled it again -- ADVICE r1)
     const int64_t min_add = (T / 8 < 100 ? T / 8 : 100) * 2;
     int64_t N = 1;
-    while (N < T + 2 * min_add) N <<= 1;
+    while (N < T + min_add) N <<= 1;
     const int64_t npad = N - T;
     p.N = N;
     p.pad0 = npad / 2;

@@ -421,7 +421,12 @@ int launch_vq_dma(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t
 int lbm_vq_hist_launch(const int64_t* idx, unsigned long long* hist, int64_t N, int K, hipStream_t st) {
     int64_t blocks = (N + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)blocks), dim3(256), (size_t)K * sizeof(unsigned int), st, idx, hist, N, K);
+    const size_t lds = (size_t)K * sizeof(unsigned int);      // one private bin per code: 128 KiB at K = 32768
+    if (lds > 48 * 1024) {                                    // beyond the default dynamic-LDS limit: opt in (160 KB per CU on gfx950)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin(hist): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)blocks), dim3(256), lds, st, idx, hist, N, K);
     return lbm::check_launch("lbm_vq_argmin(hist)");
 }
 
@@ -464,10 +469,7 @@ extern "C" int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, in
     if (rc != LBM_OK) return rc;
     if (hist_or_null != nullptr) {
         LBM_REQUIRE(K <= 32768, LBM_EUNSUPPORTED, "lbm_vq_argmin_f32: histogram supports K <= 32768");
-        int64_t blocks = (N + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(hist_kernel, dim3((unsigned)blocks), dim3(256), (size_t)K * sizeof(unsigned int), st, idx_out, hist_or_null, N, K);
-        rc = lbm::check_launch("lbm_vq_argmin_f32(hist)");
+        rc = lbm_vq_hist_launch(idx_out, hist_or_null, N, K, st);
     }
     return rc;
 }

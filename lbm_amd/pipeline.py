@@ -50,8 +50,15 @@ class PipelineConfig:
 
 class EpochPipeline:
     def __init__(self, cfg: PipelineConfig, taps, A, b, encoder: Optional[dict], codebook, device=None):
+        dev = torch.device("cuda") if device is None else torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
+        with torch.cuda.device(dev):       # tables are built on, and launches go to, the pipeline's own device
+            self._init(cfg, taps, A, b, encoder, codebook)
+
+    def _init(self, cfg, taps, A, b, encoder, codebook):
         self.cfg = cfg
-        self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.lib = _lib.load()
         f32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64)).to(self.dev, torch.float32).contiguous()  # noqa: E731
         self.taps = f32(taps) if taps is not None else None
@@ -125,7 +132,14 @@ class EpochPipeline:
 
     # ------------------------------------------------------------------ one chunk
     def run(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """x: [E, C, T] float32 CUDA tensor.  Returns views into the pipeline's buffers (valid until the next run)."""
+        """x: [E, C, T] float32 CUDA tensor on the pipeline's device.  Returns views into the pipeline's buffers (valid
+        until the next run).  Kernels are enqueued on that device's current stream."""
+        if x.is_cuda and x.device != self.dev:
+            raise ValueError(f"x lives on {x.device}, the pipeline on {self.dev}")
+        with torch.cuda.device(self.dev):
+            return self._run(x)
+
+    def _run(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         c, lib, p, st = self.cfg, self.lib, _lib.ptr, _lib.stream_ptr()
         ev = self.stage_events
 
@@ -239,6 +253,23 @@ def gather_epoch_outputs(local: torch.Tensor, group=None) -> torch.Tensor:
     blocks = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(blocks, pad, group=group)
     return torch.cat([blk[:c] for blk, c in zip(blocks, counts)], dim=0)
+
+
+def gather_pipeline_outputs(out: Dict[str, torch.Tensor], group=None, names: Sequence[str] = ("tokens", "psd", "bandpower", "keep"),
+                            drop_rejected: bool = False) -> Dict[str, torch.Tensor]:
+    """The exchange step of the path: every per-epoch array of a rank's outputs all-gathered in rank order,
+    i.e. the order np.concatenate gives the reference's per-batch lists (training/model.py:423, multi-train/withpsd.py:394-414).
+    ``drop_rejected`` first removes the epochs whose keep flag is 0 (epochs.drop_bad, multi-train/withpsd.py:219): shards then
+    differ in length and the counts travel first (gather_epoch_outputs).  Every rank of the group must call this."""
+    sel = None
+    if drop_rejected:
+        sel = out["keep"].to(torch.bool)
+    res = {}
+    for k in names:
+        if k in out:
+            v = out[k] if sel is None else out[k][sel]
+            res[k] = gather_epoch_outputs(v, group)
+    return res
 
 
 def allreduce_hist(hist: torch.Tensor, group=None) -> torch.Tensor:

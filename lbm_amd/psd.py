@@ -29,6 +29,7 @@ def welch_tables(device, n_fft: int, n_per_seg: int, window: str, bin_lo: int, b
         t = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device)
         _lib.check(lib.lbm_welch_tables_init(_lib.ptr(t), n_fft, n_per_seg, _WINDOWS[window], bin_lo, bin_hi,
                                              _lib.stream_ptr()), "lbm_welch_tables_init")
+        torch.cuda.current_stream().synchronize()   # one-off: the cached table is reused from other streams without an event
         _tables[key] = t
     return t
 

@@ -288,6 +288,9 @@ class VectorQuantizerEMA(nn.Module):
                     dist.all_reduce(dw, group=group)
                 vq_ema_apply(self.ema_cluster_size, self.ema_w, self.embedding.weight.data, dw, counts, self.decay,
                              self.epsilon)
+                # the kernel rewrote the codebook through its raw pointer (no autograd version bump): the cached |e|^2
+                # belongs to the old rows (the reference recomputes sum(weight**2) every call, training/model.py:91)
+                self._ee_key = self._ee = None
         if self.training or grad_path:
             e_latent_loss = F.mse_loss(quantized.detach(), inputs)
             q_latent_loss = F.mse_loss(quantized, inputs.detach())

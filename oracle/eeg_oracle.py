@@ -208,7 +208,7 @@ def resample(x, up=1.0, down=1.0):
     ratio = float(up) / float(down)
     final_len = int(round(ratio * T))
     min_add = min(T // 8, 100) * 2
-    npad = 2 ** int(np.ceil(np.log2(T + 2 * min_add))) - T
+    npad = 2 ** int(np.ceil(np.log2(T + min_add))) - T
     npads = np.array([npad // 2, npad - npad // 2])
     orig_len = T + npad
     new_len = max(int(round(ratio * orig_len)), 1)

@@ -1,0 +1,88 @@
+"""bench.py --gpus N: the launcher's argument / environment plumbing (CPU; the rank processes here are a stand-in script)."""
+import json
+import os
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+STUB = textwrap.dedent("""
+    import json, os, sys, time
+    r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    if "--fail-rank" in sys.argv and r == int(sys.argv[sys.argv.index("--fail-rank") + 1]):
+        sys.exit(3)
+    if "--hang-others" in sys.argv and r != int(sys.argv[sys.argv.index("--fail-rank") + 1]):
+        time.sleep(60)            # a rank waiting in a collective for the one that died
+    if r == 0:
+        print("some library chatter")
+        print(json.dumps({"n_gpus": w, "argv": sys.argv[1:]}))
+    """)
+
+
+@pytest.fixture
+def stub(tmp_path):
+    p = tmp_path / "rank_stub.py"
+    p.write_text(STUB)
+    return str(p)
+
+
+def test_rank_env_is_what_torchrun_sets():
+    env = bench.rank_env({"PATH": "/bin", "WORLD_SIZE": "9"}, 3, 8, 29512)
+    assert env["RANK"] == "3" and env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8" and env["LOCAL_WORLD_SIZE"] == "8"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "29512" and env["PATH"] == "/bin"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert bench.rank_env({"HSA_ENABLE_IPC_MODE_LEGACY": "1"}, 0, 2, 1)["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"   # caller's choice kept
+
+
+def test_launcher_starts_n_ranks_and_relays_rank0_json(stub, capfd):
+    rc = bench.launch_ranks(4, ["--gpus", "4", "--steps", "2"], script=stub)
+    out, err = capfd.readouterr()
+    assert rc == 0
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1                                       # ONE JSON line on stdout; chatter goes to stderr
+    assert json.loads(lines[0]) == {"n_gpus": 4, "argv": ["--gpus", "4", "--steps", "2"]}
+    assert "some library chatter" in err
+
+
+def test_launcher_fails_when_any_rank_fails_and_stops_the_others(stub, capfd):
+    import time
+    t0 = time.time()
+    rc = bench.launch_ranks(3, ["--fail-rank", "1", "--hang-others"], script=stub)
+    assert rc != 0 and time.time() - t0 < 30                     # did not wait for the hung ranks
+    assert "rank 1 exited with code 3" in capfd.readouterr().err
+
+
+def test_launcher_fails_without_a_json_line(stub, capfd):
+    assert bench.launch_ranks(2, ["--fail-rank", "0"], script=stub) != 0
+
+
+def test_gpus_flag_must_match_world_size(monkeypatch):
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "1"])
+    assert "WORLD_SIZE=2" in str(e.value)
+
+
+def test_gpus_flag_launches_when_no_world_size(monkeypatch):
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    seen = {}
+    monkeypatch.setattr(bench, "launch_ranks", lambda world, argv: seen.update(world=world, argv=argv) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main(["--gpus", "8", "--steps", "1"])
+    assert e.value.code == 0 and seen == {"world": 8, "argv": ["--gpus", "8", "--steps", "1"]}
+
+
+def test_parent_module_import_does_not_load_the_hip_library():
+    """The launcher parent must stay free of GPU state: importing bench must not import the product package."""
+    import subprocess
+    code = "import sys; sys.path.insert(0, %r); import bench; assert 'lbm_amd' not in sys.modules and bench.lbm_amd is None" % ROOT
+    subprocess.run([sys.executable, "-c", code], check=True)

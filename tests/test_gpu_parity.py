@@ -467,6 +467,83 @@ def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
     assert gi.shape == (1024,) and gi.dtype == torch.int64
 
 
+def test_vq_forward_tail_kernels_with_reference_indices(shipped, vq_golden):
+    """a13 (training/model.py:100,130-144), independent of argmin near-ties: lbm_vq_gather_loss_f32 fed the REFERENCE's
+    indices and lbm_perplexity_u64 fed the REFERENCE's counts must give the reference's quantized / loss / perplexity."""
+    cb = shipped["vq_layer.embedding.weight"]
+    cbd = torch.from_numpy(cb).to(DEV)
+    flat = torch.from_numpy(vq_golden["vqfwd_in"].reshape(-1, 256)).to(DEV)
+    ridx = torch.from_numpy(vq_golden["vqfwd_indices"].reshape(-1)).to(DEV)
+    q, err = lbm_amd.vq_gather_loss(flat, cbd, ridx)
+    np.testing.assert_array_equal(q.cpu().numpy().reshape(vq_golden["vqfwd_quantized"].shape), vq_golden["vqfwd_quantized"])
+    mse = float(err[0]) / flat.numel()
+    np.testing.assert_allclose((1.0 + 0.25) * mse, float(vq_golden["vqfwd_loss"]), rtol=1e-5)
+    counts = torch.bincount(ridx, minlength=512)
+    perp = lbm_amd.perplexity_from_hist(counts)
+    np.testing.assert_allclose(float(perp), float(vq_golden["vqfwd_perplexity"]), rtol=1e-5)
+    # want_quantized=False leaves the loss unchanged; the sum is ADDED to (caller zeroes)
+    _, err2 = lbm_amd.vq_gather_loss(flat, cbd, ridx, want_quantized=False)
+    assert float(err2[0]) == float(err[0])
+    # the EMA-step golden (larger input, 512 rows): loss of the training forward = same formula on the pre-update codebook
+    flat_e = torch.from_numpy(vq_golden["ema_in"].reshape(-1, 256)).to(DEV)
+    ridx_e = torch.from_numpy(vq_golden["ema_idx"].reshape(-1)).to(DEV)
+    _, err_e = lbm_amd.vq_gather_loss(flat_e, cbd, ridx_e, want_quantized=False)
+    np.testing.assert_allclose(1.25 * float(err_e[0]) / flat_e.numel(), float(vq_golden["ema_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(float(lbm_amd.perplexity_from_hist(torch.bincount(ridx_e, minlength=512))),
+                               float(vq_golden["ema_perplexity"]), rtol=1e-5)
+    # perplexity against the oracle on ragged K and skewed counts
+    rs = np.random.RandomState(4)
+    for K in (1, 7, 512, 8192):
+        c = (rs.exponential(3.0, K) * (rs.rand(K) > 0.4)).astype(np.int64)
+        c[0] += 1
+        got = float(lbm_amd.perplexity_from_hist(torch.from_numpy(c).to(DEV)))
+        np.testing.assert_allclose(got, orc.perplexity_from_counts(c), rtol=2e-5)
+
+
+def test_vq_ema_two_training_steps_use_the_updated_codebook(shipped, vq_golden):
+    """Two training-mode forwards in a row under no_grad, no optimizer: the second step's argmin must run against
+    the codebook the first step's EMA kernel wrote -- with ITS row norms, not the cached ones."""
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
+    vq = m.vq_layer.to(DEV).train()
+    rs = np.random.RandomState(8)
+    x1 = vq_golden["ema_in"]
+    x2 = (vq_golden["ema_in"][::-1] * 1.5 + 0.3 * rs.randn(*x1.shape)).astype(np.float32)
+    with torch.no_grad():
+        vq.decay = 0.5                                  # a large step, so the codebook (and its norms) really move
+        _, _, _, idx1 = vq(torch.from_numpy(x1).to(DEV))
+        w1 = vq.embedding.weight.detach().cpu().numpy().copy()
+        _, _, _, idx2 = vq(torch.from_numpy(x2).to(DEV))
+    # oracle: step 1 with the build's own step-1 indices, then argmin of step 2 against the UPDATED codebook
+    st = {"ema_cluster_size": shipped["vq_layer.ema_cluster_size"], "ema_w": shipped["vq_layer.ema_w"]}
+    cs, ew, w_or = orc.ema_update(st, x1.reshape(-1, 256), idx1.cpu().numpy().reshape(-1), decay=0.5)
+    np.testing.assert_allclose(w1, w_or, rtol=1e-5, atol=1e-6)
+    assert np.abs(w1 - shipped["vq_layer.embedding.weight"]).max() > 1e-2
+    flat2 = x2.reshape(-1, 256)
+    ref2 = orc.vq_argmin(flat2, w1)
+    got2 = idx2.cpu().numpy().reshape(-1)
+    assert orc.vq_near_tie_ok(flat2, w1, got2, ref2).all()
+    assert (got2 == ref2).mean() >= 0.97
+    stale = orc.vq_argmin(flat2, shipped["vq_layer.embedding.weight"])
+    assert (stale != ref2).mean() > 0.05               # the test can tell the two codebooks apart
+
+
+def test_vq_histogram_up_to_32768_codes():
+    """hist_kernel keeps one LDS bin per code: 128 KiB at K = 32768 (opt-in dynamic LDS).  Counts bit-exact."""
+    rs = np.random.RandomState(6)
+    for K in (16384, 16392, 32768):
+        cb = rs.randn(K, 8).astype(np.float32)
+        pick = rs.randint(0, K, 20000)
+        x = cb[pick] + 0.01 * rs.randn(20000, 8).astype(np.float32)
+        hist = torch.zeros(K, dtype=torch.int64, device=DEV)
+        idx = lbm_amd.vq_argmin(torch.from_numpy(x).to(DEV), torch.from_numpy(cb).to(DEV), hist=hist).cpu().numpy()
+        assert np.array_equal(hist.cpu().numpy(), np.bincount(idx, minlength=K))
+        assert (idx == pick).mean() > 0.99
+    with pytest.raises(NotImplementedError):
+        K = 32776
+        lbm_amd.vq_argmin(torch.zeros(4, 8, device=DEV), torch.zeros(K, 8, device=DEV), hist=torch.zeros(K, dtype=torch.int64, device=DEV))
+
+
 def test_vq_ema_training_step_golden(shipped, vq_golden):
     """VectorQuantizerEMA.forward in training mode: EMA buffers and codebook after one step (training/model.py:103-126)."""
     m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
@@ -603,6 +680,32 @@ def test_pipeline_without_cleaned_output(shipped):
         assert torch.equal(out[k], ref[k]), k
     assert _psd_err(out["psd"].cpu().numpy(), ref["psd"].cpu().numpy().astype(np.float64)) <= 4.0
     np.testing.assert_allclose(out["bandpower"].cpu().numpy(), ref["bandpower"].cpu().numpy(), rtol=2e-6)
+
+
+def test_pipeline_features_only_no_tokenizer(shipped):
+    """BASELINE config 2's branch (PSD + band-power features only): do_tokenize=False builds no encoder / codebook state,
+    returns no tokens, and its PSD / band powers / keep mask equal the full pipeline's bit for bit; with do_filter=False and
+    do_ica=False on top it is Welch + band power straight on the input, checked against the oracle."""
+    pipe, taps, A, b = _make_pipeline(shipped, T=1500)
+    cfg = lbm_amd.PipelineConfig(do_tokenize=False)
+    pipe2 = lbm_amd.EpochPipeline(cfg, taps, A, b, None, None)
+    x = (synth_epochs(24, 30, 1500, seed=14) * 2.0)
+    x[2, 9, 40] -= 1e-2
+    xd = x.to(DEV)
+    ref = {k: v.clone() for k, v in pipe.run(xd).items()}
+    out = pipe2.run(xd)
+    assert "tokens" not in out and "hist" not in out and "standardized" not in out
+    for k in ("psd", "bandpower", "keep", "cleaned"):
+        assert torch.equal(out[k], ref[k]), k
+    cfg3 = lbm_amd.PipelineConfig(do_tokenize=False, do_filter=False, do_ica=False, emit_cleaned=False)
+    out3 = lbm_amd.EpochPipeline(cfg3, None, None, None, None, None).run(xd)
+    assert set(out3) == {"psd", "bandpower", "keep"}
+    x64 = x.numpy().astype(np.float64)
+    want_psd, freqs = orc.welch_psd(x64, 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann")
+    assert _psd_err(out3["psd"].cpu().numpy(), want_psd) <= 1.0
+    np.testing.assert_allclose(out3["bandpower"].cpu().numpy(), np.stack(orc.band_powers(want_psd, freqs), axis=-1), rtol=2e-6)
+    assert np.array_equal(out3["keep"].cpu().numpy().astype(bool), orc.ptp_keep_mask(x64, 150e-6))
+    assert out3["keep"].cpu().numpy().tolist().count(0) == 1
 
 
 def test_pipeline_bf16x6_quantizer_tokens(shipped):
@@ -787,7 +890,9 @@ def test_vq_full_size_every_row_is_a_minimum(shipped):
 
 # ------------------------------------------------------------------------------------------------ 8(f)-4 resample
 @pytest.mark.parametrize("T,up,down,rows", [(5000, 1, 2, 3), (1001, 1, 2, 2), (30000, 250, 1000, 2), (65539, 250, 500, 1), (3000, 2, 1, 2),
-                                            (70, 1, 2, 1), (300000, 1, 2, 70)])
+                                            (70, 1, 2, 1), (300000, 1, 2, 70),
+                                            (2 ** 17 - 300, 1, 2, 2),     # T + min_add <= 2^17 < T + 2 min_add: MNE pads to 2^17
+                                            (2 ** 12 - 150, 1, 2, 1)])
 def test_resample_matches_oracle(T, up, down, rows):
     """raw.resample (preprocessing_unsupervised.py:37): FFT resampling with MNE's auto padding, vs the float64 oracle."""
     rs = np.random.RandomState(T)
