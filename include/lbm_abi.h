@@ -141,6 +141,18 @@ int lbm_channel_moments_f32(const float* x, const uint8_t* keep, double* row_ws,
 int lbm_channel_scale_f32(const float* x, float* y, const float* mean, const float* scale, int64_t E,
                           int32_t C, int32_t T, lbm_stream_t stream);
 
+/* lbm_channel_moments_f32 without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it
+ * exists for callers that cannot allocate device memory around the call -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same arguments (minus row_ws) and bit-identical moments; the E*C*2 doubles of
+ * per-row partial sums live in a static device array inside the library (16 MiB, held by every GPU the library has run
+ * this call on until the process ends), whose address is resolved once per device at the first call on that device.
+ * Limit: E * C <= LBM_STATIC_MOMENTS_MAX_ROWS, otherwise LBM_EUNSUPPORTED (use lbm_channel_moments_f32).
+ * All calls on one GPU share that array: calls that may overlap on one GPU (different streams, different threads) race --
+ * serialise them.  The call itself makes no hipMalloc / hipFree and allocates nothing on the host. */
+#define LBM_STATIC_MOMENTS_MAX_ROWS (1 << 20)
+int lbm_channel_moments_static_f32(const float* x, const uint8_t* keep, double* moments, int64_t E, int32_t C,
+                                   int32_t T, lbm_stream_t stream);
+
 /* ---- a7: Welch PSD ----------------------------------------------------------------------------------
  * Replaces epochs.compute_psd(method='welch', fmin, fmax, n_fft, window, n_overlap, average) +
  * spectrum.get_data() at multi-train/withpsd.py:236-250 and raw.compute_psd(fmin, fmax, n_fft=512) at

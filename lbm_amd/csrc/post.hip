@@ -4,6 +4,8 @@
 // row and keep it in registers (NV values per thread), so the row is read from HBM exactly once:
 // TPR = 64 (one wavefront per row, shuffle reductions only, no barrier) up to T = 2560, a 256- or
 // 1024-thread workgroup per row beyond that.  Two-pass mean/variance in fp32 on register data.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -224,20 +226,73 @@ extern "C" int lbm_epoch_post_f32(const float* x, float* y_base, float* y_std, u
     return launch_post<1024>(x, y_base, y_std, keep, rows, C, T, n_baseline, ptp_thresh, standardize_mode, eps, st);
 }
 
+namespace {
+int launch_channel_moments(const char* who, const float* x, const uint8_t* keep, double* row_ws, double* moments, int64_t E, int C,
+                           int T, hipStream_t st) {
+    const int64_t rows = E * C;
+    if (rows > 0) {
+        const int64_t blocks = (rows + 3) / 4;
+        if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "%s: grid too large", who);
+        hipLaunchKernelGGL(row_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, keep, row_ws, rows, C, T);
+    }
+    hipLaunchKernelGGL(channel_moments_kernel, dim3(C), dim3(256), 0, st, row_ws, keep, moments, E, C, T);
+    return lbm::check_launch(who);
+}
+}  // namespace
+
 extern "C" int lbm_channel_moments_f32(const float* x, const uint8_t* keep, double* row_ws, double* moments, int64_t E,
                                        int32_t C, int32_t T, lbm_stream_t stream) {
     LBM_REQUIRE(E >= 0 && C >= 1 && T >= 0, LBM_EINVAL, "lbm_channel_moments_f32: bad sizes");
     LBM_REQUIRE(moments != nullptr, LBM_EINVAL, "lbm_channel_moments_f32: NULL moments");
     LBM_REQUIRE(E == 0 || (x != nullptr && row_ws != nullptr), LBM_EINVAL, "lbm_channel_moments_f32: NULL pointer");
-    hipStream_t st = lbm::as_stream(stream);
-    const int64_t rows = E * C;
-    if (rows > 0) {
-        const int64_t blocks = (rows + 3) / 4;
-        LBM_REQUIRE(blocks <= 0x7fffffffLL, LBM_EUNSUPPORTED, "lbm_channel_moments_f32: grid too large");
-        hipLaunchKernelGGL(row_moments_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, keep, row_ws, rows, C, T);
+    return launch_channel_moments("lbm_channel_moments_f32", x, keep, row_ws, moments, E, C, T, lbm::as_stream(stream));
+}
+
+// ---- the one entry point that allocates nothing and needs no workspace argument ------------------------------------------
+// lbm_channel_moments_f32's per-row partial sums (E*C*2 doubles) live in a file-scope device array instead of a caller buffer.
+// Every GPU the library runs on holds its own copy (16 MiB) at its own address until the process ends; the array's NAME is a
+// host-side stand-in, so the device address is looked up once per device with hipGetSymbolAddress and only that pointer is
+// ever handed to kernels.
+static __device__ __align__(256) double scratch[2 * LBM_STATIC_MOMENTS_MAX_ROWS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[kMaxDevices] = {};
+
+// device address of `scratch` on the CURRENT device (looked up at the first call on that device, then cached)
+int scratch_of_current_device(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_channel_moments_static_f32: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return lbm::fail(LBM_EUNSUPPORTED, "lbm_channel_moments_static_f32: device %d (max %d)", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr)
+            return lbm::fail(LBM_ELAUNCH, "lbm_channel_moments_static_f32: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                             hipGetErrorString(e));
+        g_scratch_ptr[dev] = static_cast<double*>(p);
     }
-    hipLaunchKernelGGL(channel_moments_kernel, dim3(C), dim3(256), 0, st, row_ws, keep, moments, E, C, T);
-    return lbm::check_launch("lbm_channel_moments_f32");
+    *out = g_scratch_ptr[dev];
+    return LBM_OK;
+}
+}  // namespace
+
+extern "C" int lbm_channel_moments_static_f32(const float* x, const uint8_t* keep, double* moments, int64_t E, int32_t C,
+                                              int32_t T, lbm_stream_t stream) {
+    LBM_REQUIRE(E >= 0 && C >= 1 && T >= 0, LBM_EINVAL, "lbm_channel_moments_static_f32: bad sizes");
+    LBM_REQUIRE(moments != nullptr, LBM_EINVAL, "lbm_channel_moments_static_f32: NULL moments");
+    LBM_REQUIRE(E == 0 || x != nullptr, LBM_EINVAL, "lbm_channel_moments_static_f32: NULL pointer");
+    LBM_REQUIRE(E <= LBM_STATIC_MOMENTS_MAX_ROWS / C, LBM_EUNSUPPORTED,
+                "lbm_channel_moments_static_f32: E*C = %lld rows exceed the static scratch (%lld rows): use lbm_channel_moments_f32 "
+                "with a caller workspace", (long long)E * C, (long long)LBM_STATIC_MOMENTS_MAX_ROWS);
+    double* ws = nullptr;
+    const int rc = scratch_of_current_device(&ws);
+    if (rc != LBM_OK) return rc;
+    // rows [0, E*C) of the scratch are fully rewritten by the row pass before the channel pass reads them: nothing to clear
+    return launch_channel_moments("lbm_channel_moments_static_f32", x, keep, ws, moments, E, C, T, lbm::as_stream(stream));
 }
 
 extern "C" int lbm_channel_scale_f32(const float* x, float* y, const float* mean, const float* scale, int64_t E,

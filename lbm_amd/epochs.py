@@ -106,12 +106,23 @@ class Scaler:
         self.with_mean, self.with_std = with_mean, with_std
         self.mean_ = self.scale_ = self.moments_ = None
 
-    def moments(self, x: torch.Tensor, keep: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """[C, 3] float64 {sum, sum of squares, count}: the quantity to all-reduce across ranks."""
+    def moments(self, x: torch.Tensor, keep: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                static_scratch: bool = False) -> torch.Tensor:
+        """[C, 3] float64 {sum, sum of squares, count}: the quantity to all-reduce across ranks.
+        ``static_scratch=True`` (with a caller-provided ``out`` and a uint8 ``keep``) goes through
+        ``lbm_channel_moments_static_f32``: no workspace, no allocation -- for callers under graph capture."""
         x = _lib.dev_f32(x)
         E, Cc, T = x.shape
+        if static_scratch:
+            if out is None or out.dtype != torch.float64 or tuple(out.shape) != (Cc, 3) or not out.is_contiguous():
+                raise ValueError("static_scratch needs out = contiguous float64 [C, 3] on the device")
+            if keep is not None and (keep.dtype != torch.uint8 or not keep.is_contiguous()):
+                raise ValueError("static_scratch needs keep as a contiguous uint8 tensor")
+            _lib.check(_lib.load().lbm_channel_moments_static_f32(_lib.ptr(x), _lib.ptr(keep), _lib.ptr(out), E, Cc, T,
+                                                                  _lib.stream_ptr()), "lbm_channel_moments_static_f32")
+            return out
         ws = torch.empty((max(E * Cc, 1), 2), dtype=torch.float64, device=x.device)
-        mom = torch.empty((Cc, 3), dtype=torch.float64, device=x.device)
+        mom = torch.empty((Cc, 3), dtype=torch.float64, device=x.device) if out is None else out
         k = keep.to(torch.uint8).contiguous() if keep is not None else None
         _lib.check(_lib.load().lbm_channel_moments_f32(_lib.ptr(x), _lib.ptr(k), _lib.ptr(ws), _lib.ptr(mom), E, Cc, T,
                                                        _lib.stream_ptr()), "lbm_channel_moments_f32")
