@@ -524,8 +524,12 @@ def test_vq_ema_two_training_steps_use_the_updated_codebook(shipped, vq_golden):
     got2 = idx2.cpu().numpy().reshape(-1)
     assert orc.vq_near_tie_ok(flat2, w1, got2, ref2).all()
     assert (got2 == ref2).mean() >= 0.97
-    stale = orc.vq_argmin(flat2, shipped["vq_layer.embedding.weight"])
-    assert (stale != ref2).mean() > 0.05               # the test can tell the two codebooks apart
+    # what the round-1 bug computed: the NEW codebook with the OLD row norms.  It must differ from the right answer by
+    # more than near-ties, or this test could not have caught it
+    w0 = shipped["vq_layer.embedding.weight"].astype(np.float64)
+    d_stale = (w0 * w0).sum(1)[None, :] - 2.0 * (flat2.astype(np.float64) @ w1.astype(np.float64).T)
+    stale = d_stale.argmin(axis=1)
+    assert (~orc.vq_near_tie_ok(flat2, w1, stale, ref2)).sum() >= 3
 
 
 def test_vq_histogram_up_to_32768_codes():
