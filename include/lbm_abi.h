@@ -131,6 +131,23 @@ int lbm_epoch_post_f32(const float* x, float* y_base, float* y_std, uint8_t* kee
                        int32_t T, int32_t n_baseline, float ptp_thresh, int32_t standardize_mode, float eps,
                        lbm_stream_t stream);
 
+/* a3 + a4 / a5 / a6 fused: the ICA channel map and the epoch post-processing in ONE pass over the epoch (one read, one
+ * write per requested output instead of affine r+w then post r+w).  Replaces ica.apply (training/preprocess.py:144,
+ * multi-train/withpsd.py:152) followed by mne.Epochs(..., baseline=(None, 0)) (:262-271), reject=dict(eeg=150e-6)
+ * (multi-train/withpsd.py:213-219) and the per-epoch per-channel z-score (training/preprocess.py:279-287):
+ *   y = A x + b;  base = mean(y[:n_baseline]);  y_base = y - base;  keep[e] = 0 if any channel's max - min > ptp_thresh;
+ *   y_std = (y_base - mean_t) / (std_t + eps);  row_scale[e, o] = std_t + eps.
+ * x: [E, Cin, T]; A: [Cout, Cin]; b: [Cout] or NULL; y_base, y_std: [E, Cout, T] or NULL (not written); row_scale: [E, Cout]
+ * or NULL; keep: [E] or NULL.  y_std / row_scale need standardize_mode == LBM_STD_EPOCH_CHANNEL.  row_scale is what
+ * lbm_welch_scaled_f32 takes to compute the PSD of y_base from y_std, so y_base need not exist at all.
+ * fp32 MFMA (exact ascending-channel fmaf chain starting from b).  Supported: Cin <= 64, Cout <= 256, T <= 1536
+ * (lbm_affine_post_supported returns 1); otherwise LBM_EUNSUPPORTED -- use lbm_affine_ch_f32 + lbm_epoch_post_f32.
+ * Outputs must not overlap x. */
+int lbm_affine_post_supported(int32_t Cin, int32_t Cout, int32_t T);
+int lbm_affine_post_f32(const float* x, const float* A, const float* b, float* y_base, float* y_std, float* row_scale,
+                        uint8_t* keep, int64_t E, int32_t Cin, int32_t Cout, int32_t T, int32_t n_baseline,
+                        float ptp_thresh, int32_t standardize_mode, float eps, lbm_stream_t stream);
+
 /* mne.decoding.Scaler(scalings='mean') (multi-train/withpsd.py:267-270) = fit + transform:
  * lbm_channel_moments_f32: moments[c] = {sum, sum of squares, sample count} in float64 over all kept
  *   epochs x time (keep == NULL: all epochs), reduced in a fixed order (deterministic).
@@ -180,6 +197,14 @@ int lbm_welch_tables_init(void* tables, int32_t nfft, int32_t nperseg, int32_t w
 int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int64_t rows, int32_t T, float fs,
                   int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
                   int32_t bin_hi, int32_t average_mode, lbm_stream_t stream);
+
+/* lbm_welch_f32 of rows that were rescaled per row: psd[r] = row_scale[r]^2 * Welch(x[r]).  With x = the z-scored epochs and
+ * row_scale = std_t + eps (lbm_affine_post_f32) this is the PSD of the cleaned, un-standardised epochs of
+ * multi-train/withpsd.py:236-250 (Welch removes each segment's mean, so the z-score's offset never matters) without those
+ * epochs ever being written.  Per-segment outputs (seg_or_null) are scaled the same way. */
+int lbm_welch_scaled_f32(const float* x, const float* row_scale, float* psd, float* seg_or_null, int64_t rows, int32_t T,
+                         float fs, int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
+                         int32_t bin_hi, int32_t average_mode, lbm_stream_t stream);
 
 /* ---- a8: theta/alpha/beta band powers and ratios ----------------------------------------------------
  * Replaces preprocessing_unsupervised.py:45-61 (also :102-110, failed/label.py:13-23):

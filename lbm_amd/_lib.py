@@ -39,12 +39,15 @@ SIGNATURES = {
     "lbm_resample_workspace_bytes": (C.c_size_t, [_i64, _i64, _i32, _i32]),
     "lbm_resample_fft_f32": (C.c_int, [_p, _i64, _p, _i64, _i64, _i64, _i32, _i32, _p, _p]),
     "lbm_epoch_post_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _f32, _i32, _f32, _p]),
+    "lbm_affine_post_supported": (C.c_int, [_i32, _i32, _i32]),
+    "lbm_affine_post_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _f32, _p]),
     "lbm_channel_moments_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_channel_moments_static_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_channel_scale_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_welch_tables_bytes": (C.c_size_t, [_i32, _i32, _i32, _i32]),
     "lbm_welch_tables_init": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p]),
     "lbm_welch_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p]),
+    "lbm_welch_scaled_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "lbm_bandpower_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_pitched_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

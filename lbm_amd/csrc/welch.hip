@@ -134,7 +134,8 @@ __host__ __device__ inline FoldGeom fold_geom(int nfft, int T, int hop, int nseg
     return g;
 }
 
-__global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict__ x, float* __restrict__ psd, int64_t rows,
+__global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict__ x, const float* __restrict__ row_scale,
+                                                              float* __restrict__ psd, int64_t rows,
                                                               int T, double fs, FoldGeom g, const void* __restrict__ tables,
                                                               int bin_lo, int F, int64_t ngroups) {
     extern __shared__ __align__(16) float smem[];
@@ -379,14 +380,19 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
             float acc = 0.f;
             for (int s = 0; s < g.nseg; ++s) acc += s_P[(r * g.nseg + s) * kLdp + fb];
             const int k = bin_lo + fb;
-            const double sc = (k == 0 || k == g.H) ? scale : scale2;
+            double sc = (k == 0 || k == g.H) ? scale : scale2;
+            if (row_scale != nullptr) {            // x is a per-row rescaled copy (z-scored epochs): PSD(s x) = s^2 PSD(x)
+                const double rs = (double)row_scale[row0 + r];
+                sc *= rs * rs;
+            }
             psd[row0 * F + o] = (float)((double)(acc / (float)g.nseg) * sc);
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-__global__ __launch_bounds__(kThreads) void welch_kernel(const float* __restrict__ x, float* __restrict__ psd,
+__global__ __launch_bounds__(kThreads) void welch_kernel(const float* __restrict__ x, const float* __restrict__ row_scale,
+                                                         float* __restrict__ psd,
                                                          float* __restrict__ seg_out, int T, double fs, int nfft,
                                                          int nperseg, int hop, int nseg, const void* __restrict__ tables,
                                                          int bin_lo, int F, int average_mode) {
@@ -414,7 +420,8 @@ __global__ __launch_bounds__(kThreads) void welch_kernel(const float* __restrict
     }
     __syncthreads();
 
-    const double scale = 1.0 / (fs * (*tv.sum_w2));
+    double scale = 1.0 / (fs * (*tv.sum_w2));
+    if (row_scale != nullptr) scale *= (double)row_scale[row] * (double)row_scale[row];
     const int nout = nseg * F;
     for (int o = threadIdx.x; o < nout; o += kThreads) {
         const int s = o / F, k = bin_lo + (o % F);
@@ -514,9 +521,10 @@ extern "C" int lbm_welch_tables_init(void* tables, int32_t nfft, int32_t nperseg
     return lbm::check_launch("lbm_welch_tables_init");
 }
 
-extern "C" int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int64_t rows, int32_t T, float fs,
-                             int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
-                             int32_t bin_hi, int32_t average_mode, lbm_stream_t stream) {
+namespace {
+int welch_impl(const float* x, const float* row_scale, float* psd, float* seg_or_null, int64_t rows, int32_t T, float fs,
+               int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
+               int32_t bin_hi, int32_t average_mode, lbm_stream_t stream) {
     LBM_REQUIRE(rows >= 0, LBM_EINVAL, "lbm_welch_f32: negative rows");
     LBM_REQUIRE(nperseg >= 1 && nperseg <= nfft, LBM_EINVAL, "lbm_welch_f32: need 1 <= nperseg <= nfft");
     LBM_REQUIRE(nfft <= T, LBM_EINVAL, "lbm_welch_f32: n_fft (%d) is larger than the number of samples (%d)", nfft, T);
@@ -546,7 +554,7 @@ extern "C" int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int
             if (blocks > 1024) blocks = 1024;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(welch_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);
             if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_welch_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            hipLaunchKernelGGL(welch_fold_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_f, lbm::as_stream(stream), x, psd, rows, T,
+            hipLaunchKernelGGL(welch_fold_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds_f, lbm::as_stream(stream), x, row_scale, psd, rows, T,
                                (double)fs, g, tables, bin_lo, F, ngroups);
             return lbm::check_launch("lbm_welch_f32(fold)");
         }
@@ -557,9 +565,23 @@ extern "C" int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(welch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_welch_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(welch_kernel, dim3((unsigned)rows), dim3(kThreads), lds, lbm::as_stream(stream), x, psd, seg_or_null, T,
+    hipLaunchKernelGGL(welch_kernel, dim3((unsigned)rows), dim3(kThreads), lds, lbm::as_stream(stream), x, row_scale, psd, seg_or_null, T,
                        (double)fs, nfft, nperseg, hop, nseg, tables, bin_lo, F, average_mode);
     return lbm::check_launch("lbm_welch_f32");
+}
+}  // namespace
+
+extern "C" int lbm_welch_f32(const float* x, float* psd, float* seg_or_null, int64_t rows, int32_t T, float fs,
+                             int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
+                             int32_t bin_hi, int32_t average_mode, lbm_stream_t stream) {
+    return welch_impl(x, nullptr, psd, seg_or_null, rows, T, fs, nfft, nperseg, noverlap, tables, bin_lo, bin_hi, average_mode, stream);
+}
+
+extern "C" int lbm_welch_scaled_f32(const float* x, const float* row_scale, float* psd, float* seg_or_null, int64_t rows, int32_t T,
+                                    float fs, int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
+                                    int32_t bin_hi, int32_t average_mode, lbm_stream_t stream) {
+    LBM_REQUIRE(rows == 0 || row_scale != nullptr, LBM_EINVAL, "lbm_welch_scaled_f32: NULL row_scale");
+    return welch_impl(x, row_scale, psd, seg_or_null, rows, T, fs, nfft, nperseg, noverlap, tables, bin_lo, bin_hi, average_mode, stream);
 }
 
 extern "C" int lbm_bandpower_f32(const float* psd, const float* freqs, float* out, int64_t E, int32_t C, int32_t F,

@@ -86,6 +86,42 @@ def epoch_post(x: torch.Tensor, *, n_baseline: int = 0, reject: Optional[float] 
     return y_base, y_std, (keep.bool() if keep is not None else None)
 
 
+def affine_post_supported(Cin: int, Cout: int, T: int) -> bool:
+    return bool(_lib.load().lbm_affine_post_supported(int(Cin), int(Cout), int(T)))
+
+
+def affine_post(x: torch.Tensor, A, b=None, *, n_baseline: int = 0, reject: Optional[float] = None, standardize: bool = True,
+                eps: float = ZSCORE_EPSILON, want_base: bool = True):
+    """ICA channel map + baseline + peak-to-peak keep mask + z-score in ONE pass over x[E, Cin, T] (``lbm_affine_post_f32``):
+    what ``ica_apply`` followed by ``epoch_post`` computes (training/preprocess.py:144,262-287; multi-train/withpsd.py:213-219),
+    with one read and one write per requested output.  Returns a dict: ``base`` (baseline-corrected, if ``want_base``), ``std``
+    and ``row_scale`` = std_t + eps per (epoch, channel) (if ``standardize``), ``keep`` (bool, if ``reject`` is given)."""
+    x = _lib.dev_f32(x)
+    A = _lib.dev_f32(A, x.device)
+    b = _lib.dev_f32(b, x.device) if b is not None else None
+    E, Cin, T = x.shape
+    Cout = A.shape[0]
+    if A.shape[1] != Cin:
+        raise ValueError(f"A is {tuple(A.shape)}, x has {Cin} channels")
+    mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=x.device)  # noqa: E731
+    y_base = mk(E, Cout, T) if want_base else None
+    y_std = mk(E, Cout, T) if standardize else None
+    rs = mk(E, Cout) if standardize else None
+    keep = torch.empty((E,), dtype=torch.uint8, device=x.device) if reject is not None else None
+    _lib.check(_lib.load().lbm_affine_post_f32(
+        _lib.ptr(x), _lib.ptr(A), _lib.ptr(b), _lib.ptr(y_base), _lib.ptr(y_std), _lib.ptr(rs), _lib.ptr(keep), E, Cin, Cout, T,
+        int(n_baseline), float(reject) if reject is not None else math.inf,
+        _lib.STD_EPOCH_CHANNEL if standardize else _lib.STD_NONE, float(eps), _lib.stream_ptr()), "lbm_affine_post_f32")
+    out = {}
+    if want_base:
+        out["base"] = y_base
+    if standardize:
+        out["std"], out["row_scale"] = y_std, rs
+    if keep is not None:
+        out["keep"] = keep.bool()
+    return out
+
+
 def standardize_epochs(x: torch.Tensor, eps: float = ZSCORE_EPSILON) -> torch.Tensor:
     """(x - mean_t) / (std_t + eps) per epoch and channel (training/preprocess.py:282-287)."""
     x = _lib.dev_f32(x)

@@ -44,6 +44,9 @@ class PipelineConfig:
                                        # bf16 pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
     conv_method: str = "fp32"          # 'bf16x6': the encoder's 256-channel layers (3rd conv, 1x1 projection) on the bf16 MFMA
                                        # with three-piece operands (conv_bf16.hip; same accuracy vs float64 as the fp32 chain)
+    fuse_post: bool = True             # ICA affine + baseline / reject / z-score in one kernel (lbm_affine_post_f32) and Welch on the
+                                       # z-scored epochs with the per-row scale (lbm_welch_scaled_f32): 900 000 instead of
+                                       # 1 260 000 B of HBM traffic per 30x1500 epoch in the DSP front; False = the separate kernels
     fold_projection: bool = False      # tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook
                                        # (quantizer.fold_projection; no z output; equal tokens except fp32 near-ties)
 
@@ -105,6 +108,9 @@ class EpochPipeline:
             self.L2 = (self.L1 + 2 - 4) // 2 + 1
             self.S = self.L2
             self.P1, self.P2 = (self.L1 + 3) & ~3, (self.L2 + 3) & ~3   # row pitches of the activation buffers
+        # the fused ICA + post kernel needs the ICA map and a shape it supports; otherwise the separate kernels run
+        self.fused = bool(cfg.fuse_post and cfg.do_ica and self.A is not None and
+                          self.lib.lbm_affine_post_supported(cfg.n_channels, cfg.n_channels, cfg.n_times))
         self._cap = 0
         self._buf: Dict[str, torch.Tensor] = {}
         self.stage_events = None   # set to [] to record (name, start, end) HIP events per stage on the current stream
@@ -115,9 +121,15 @@ class EpochPipeline:
             return
         c, d = self.cfg, self.dev
         mk = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=d)  # noqa: E731
-        B = {"filt": mk(E, c.n_channels, c.n_times), "clean": mk(E, c.n_channels, c.n_times),
-             "std": mk(E, c.n_channels, c.n_times), "keep": mk(E, dt=torch.uint8),
-             "psd": mk(E, c.n_channels, self.F), "bp": mk(E, 6)}
+        B = {"keep": mk(E, dt=torch.uint8), "psd": mk(E, c.n_channels, self.F), "bp": mk(E, 6)}
+        if c.do_filter:
+            B["filt"] = mk(E, c.n_channels, c.n_times)
+        if c.emit_cleaned or (c.do_ica and not self.fused) or (self.fused and not c.do_tokenize):
+            B["clean"] = mk(E, c.n_channels, c.n_times)
+        if c.do_tokenize:
+            B["std"] = mk(E, c.n_channels, c.n_times)
+        if self.fused and c.do_tokenize:
+            B["rscale"] = mk(E, c.n_channels)
         if c.do_tokenize:
             # encoder activations: rows padded to a multiple of 4 floats, so every conv access is a 16-byte one
             B.update(h1=mk(E, 64, self.P1), h2=mk(E, 128, self.P2), h3=mk(E, 256, self.P2),
@@ -170,19 +182,34 @@ class EpochPipeline:
                                            _lib.PAD_REFLECT_LIMITED, st), "fir")
             cur = B["filt"]
             t0 = mark("fir", t0)
-        if c.do_ica:
-            _lib.check(lib.lbm_affine_ch_f32(p(cur), p(B["clean"]), E, C, C, T, p(self.A), p(self.b), st), "affine")
-            cur = B["clean"]
-            t0 = mark("affine", t0)
-        base = B["clean"] if c.emit_cleaned else cur      # the PSD is the same with or without the baseline offset
-        _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base) if c.emit_cleaned else None, p(B["std"]) if c.do_tokenize else None,
-                                          p(B["keep"]), E, C, T,
-                                          c.n_baseline, float(c.reject),
-                                          _lib.STD_EPOCH_CHANNEL if c.do_tokenize else _lib.STD_NONE, c.zscore_eps, st), "post")
-        t0 = mark("post", t0)
-        _lib.check(lib.lbm_welch_f32(p(base), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft, self.n_fft,
-                                     self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, _lib.AVG_MEAN, st), "welch")
-        t0 = mark("welch", t0)
+        std_mode = _lib.STD_EPOCH_CHANNEL if c.do_tokenize else _lib.STD_NONE
+        if self.fused:
+            # one pass: channel map + baseline + keep mask + z-score; the cleaned epochs are written only if someone wants them
+            base = B["clean"] if (c.emit_cleaned or not c.do_tokenize) else None
+            _lib.check(lib.lbm_affine_post_f32(p(cur), p(self.A), p(self.b), p(base), p(B["std"]) if c.do_tokenize else None,
+                                               p(B["rscale"]) if c.do_tokenize else None, p(B["keep"]), E, C, C, T, c.n_baseline,
+                                               float(c.reject), std_mode, c.zscore_eps, st), "affine_post")
+            t0 = mark("affine_post", t0)
+            if c.do_tokenize:      # PSD of the cleaned epochs from the z-scored ones: PSD(s x) = s^2 PSD(x), segment means removed
+                _lib.check(lib.lbm_welch_scaled_f32(p(B["std"]), p(B["rscale"]), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft,
+                                                    self.n_fft, self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi,
+                                                    _lib.AVG_MEAN, st), "welch")
+            else:
+                _lib.check(lib.lbm_welch_f32(p(base), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft, self.n_fft,
+                                             self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, _lib.AVG_MEAN, st), "welch")
+            t0 = mark("welch", t0)
+        else:
+            if c.do_ica:
+                _lib.check(lib.lbm_affine_ch_f32(p(cur), p(B["clean"]), E, C, C, T, p(self.A), p(self.b), st), "affine")
+                cur = B["clean"]
+                t0 = mark("affine", t0)
+            base = B["clean"] if c.emit_cleaned else cur      # the PSD is the same with or without the baseline offset
+            _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base) if c.emit_cleaned else None, p(B["std"]) if c.do_tokenize else None,
+                                              p(B["keep"]), E, C, T, c.n_baseline, float(c.reject), std_mode, c.zscore_eps, st), "post")
+            t0 = mark("post", t0)
+            _lib.check(lib.lbm_welch_f32(p(base), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft, self.n_fft,
+                                         self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, _lib.AVG_MEAN, st), "welch")
+            t0 = mark("welch", t0)
         _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
         t0 = mark("bandpower", t0)
         out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"]}

@@ -43,8 +43,10 @@ def welch_bins(sfreq: float, n_fft: int, fmin: float, fmax: float) -> Tuple[np.n
 
 
 def psd_array_welch(data, sfreq, fmin=0.0, fmax=np.inf, n_fft=256, n_overlap=0, n_per_seg=None,
-                    window="hamming", average="mean"):
-    """``mne.time_frequency.psd_array_welch`` equivalent.  Returns (psds[..., F] (or [..., F, nseg]), freqs[F])."""
+                    window="hamming", average="mean", row_scale=None):
+    """``mne.time_frequency.psd_array_welch`` equivalent.  Returns (psds[..., F] (or [..., F, nseg]), freqs[F]).
+    ``row_scale`` (one float per row of ``data``, not an MNE argument): the PSD of ``row_scale[r] * data[r]``, i.e. of the
+    un-standardised epochs when ``data`` holds z-scored ones and ``row_scale`` their ``std + eps`` (``affine_post``)."""
     if average is False:  # multi-train/withpsd.py:244 passes average=False; its comments ask for per-epoch PSD
         warnings.warn("average=False is not a valid MNE value; using 'mean' (per-epoch PSD)")
         average = "mean"
@@ -71,9 +73,17 @@ def psd_array_welch(data, sfreq, fmin=0.0, fmax=np.inf, n_fft=256, n_overlap=0, 
     lead = tuple(x.shape[:-1])
     psd = torch.empty(lead + (F,), dtype=torch.float32, device=x.device) if average is not None else None
     seg = torch.empty(lead + (F, nseg), dtype=torch.float32, device=x.device) if average is None else None
-    _lib.check(_lib.load().lbm_welch_f32(_lib.ptr(x), _lib.ptr(psd), _lib.ptr(seg), rows, T, float(sfreq), n_fft, n_per_seg,
-                                         int(n_overlap), _lib.ptr(tables), lo, hi, _AVERAGE[average], _lib.stream_ptr()),
-               "lbm_welch_f32")
+    if row_scale is not None:
+        rs = _lib.dev_f32(row_scale, x.device).reshape(-1)
+        if rs.numel() != rows:
+            raise ValueError(f"row_scale has {rs.numel()} entries for {rows} rows")
+        _lib.check(_lib.load().lbm_welch_scaled_f32(_lib.ptr(x), _lib.ptr(rs), _lib.ptr(psd), _lib.ptr(seg), rows, T, float(sfreq),
+                                                    n_fft, n_per_seg, int(n_overlap), _lib.ptr(tables), lo, hi, _AVERAGE[average],
+                                                    _lib.stream_ptr()), "lbm_welch_scaled_f32")
+    else:
+        _lib.check(_lib.load().lbm_welch_f32(_lib.ptr(x), _lib.ptr(psd), _lib.ptr(seg), rows, T, float(sfreq), n_fft, n_per_seg,
+                                             int(n_overlap), _lib.ptr(tables), lo, hi, _AVERAGE[average], _lib.stream_ptr()),
+                   "lbm_welch_f32")
     out = psd if average is not None else seg
     return (out.cpu().numpy().astype(np.float64) if was_numpy else out), freqs
 

@@ -184,6 +184,14 @@ def test_scaler_matches_oracle():
 
 
 # ------------------------------------------------------------------------------------------------ a7 Welch
+# End-to-end PSD tolerance, in units of the stage tolerance (rtol 1e-5 + atol 1e-5 * row max).  The Welch STAGE meets 1.0 on exact
+# inputs (test_welch_matches_oracle).  At the end of the chain its input already carries the fp32 rounding of the 825-tap FIR
+# (~1e-6 of the row rms per sample) and of the 30-channel ICA map (~1e-6): a PSD bin is quadratic in the signal, so those input
+# errors arrive doubled, and out-of-band-attenuated bins near 4 and 30 Hz sit 20-30 dB under the row maximum.  Measured on the
+# bench's config-1 sample: 0.05 of the stage tolerance; 2.0 is the bound asserted (round 1 allowed 4.0).
+PIPELINE_PSD_TOL = 2.0
+
+
 def _psd_err(got, want):
     got = np.asarray(got, dtype=np.float64)
     tol = 1e-5 * np.abs(want) + 1e-5 * np.abs(want).max(axis=-1, keepdims=True)
@@ -340,6 +348,83 @@ def test_conv1d_bf16x6_matches_float64(B, Cin, L, Cout, k, s, p):
     xp.as_strided((B, Cin, xp.stride(1)), xp.stride())[:, :, L:] = float("nan")
     yp = lbm_amd.conv1d(xp, w.to(DEV), b.to(DEV), s, p, True, pitched_out=True, split_tables=tab)
     assert torch.equal(yp.cpu(), y)
+
+
+# ------------------------------------------------------------------------------------------------ a3 + a4-a6 fused
+@pytest.mark.parametrize("E,Cin,Cout,T,nb", [(5, 30, 30, 1500, 251), (4, 30, 30, 1001, 251), (3, 64, 64, 700, 100), (6, 5, 3, 37, 9),
+                                             (2, 31, 40, 1534, 0), (3, 1, 2, 130, 1), (2, 33, 33, 1536, 1536), (7, 2, 1, 5, 5)])
+def test_affine_post_fused_matches_oracle(E, Cin, Cout, T, nb):
+    """lbm_affine_post_f32 (ica.apply + baseline + reject + z-score in one pass) against the oracle's separate steps
+    (training/preprocess.py:144,262-287; multi-train/withpsd.py:213-219): ragged channel counts (odd Cin, Cin = 1, Cout > 32),
+    T not a multiple of 4, single- and multi-wave rows, baseline windows of 0 / 1 / all samples."""
+    rs = np.random.RandomState(E * 1000 + T)
+    x = (synth_epochs(E, Cin, T, seed=E + T).numpy() if T >= 64 else rs.randn(E, Cin, T).astype(np.float32) * 1e-5)
+    x = x * np.float32(2.0) + np.float32(3e-6) * rs.randn(1, Cin, 1).astype(np.float32)
+    x[E // 2, 0, T // 2] += np.float32(4e-4)                              # one artefact -> one epoch may be rejected
+    A = rs.randn(Cout, Cin) / np.sqrt(Cin)
+    b = rs.randn(Cout) * 1e-5
+    out = lbm_amd.affine_post(torch.from_numpy(x).to(DEV), A, b, n_baseline=nb, reject=150e-6, standardize=True)
+    y = np.einsum("oc,ect->eot", A, x.astype(np.float64)) + b[None, :, None]
+    wb = orc.baseline_correct(y, nb) if nb > 0 else y
+    ws = orc.zscore_epoch_channel(wb, 1e-6)
+    scale = np.sqrt((y ** 2).mean()) + 1e-300
+    assert float(np.abs(out["base"].cpu().numpy() - wb).max() / scale) <= 1e-5
+    assert float(np.abs(out["std"].cpu().numpy() - ws).max()) <= 2e-5
+    np.testing.assert_allclose(out["row_scale"].cpu().numpy(), wb.std(axis=-1) + 1e-6, rtol=1e-5)
+    ptp = y.max(axis=-1) - y.min(axis=-1)
+    safe = np.abs(ptp - 150e-6).min(axis=1) > 1e-9                        # epochs whose verdict does not hang on rounding
+    assert np.array_equal(out["keep"].cpu().numpy()[safe], orc.ptp_keep_mask(y, 150e-6)[safe])
+    # the separate kernels give the same thing (to fp32 rounding), and outputs can be switched off one by one
+    xs = torch.from_numpy(x).to(DEV)
+    clean = lbm_amd.affine_channels(xs, A, b)
+    b2, s2, k2 = lbm_amd.epoch_post(clean, n_baseline=nb, reject=150e-6, standardize=True)
+    assert float((out["base"] - b2).abs().max() / scale) <= 1e-5 and float((out["std"] - s2).abs().max()) <= 2e-5
+    only_std = lbm_amd.affine_post(xs, A, b, n_baseline=nb, standardize=True, want_base=False)
+    assert set(only_std) == {"std", "row_scale"} and torch.equal(only_std["std"], out["std"])
+    only_base = lbm_amd.affine_post(xs, A, b, n_baseline=nb, reject=150e-6, standardize=False)
+    assert set(only_base) == {"base", "keep"} and torch.equal(only_base["base"], out["base"]) and torch.equal(only_base["keep"], out["keep"])
+
+
+def test_affine_post_limits_and_welch_from_standardized_rows():
+    """Shapes beyond the fused kernel return LBM_EUNSUPPORTED (the separate kernels remain); lbm_welch_scaled_f32 on the z-scored
+    epochs with row_scale reproduces the PSD of the cleaned epochs (multi-train/withpsd.py:236-250)."""
+    assert lbm_amd.affine_post_supported(30, 30, 1500) and lbm_amd.affine_post_supported(64, 256, 1536)
+    assert not lbm_amd.affine_post_supported(30, 30, 1537) and not lbm_amd.affine_post_supported(65, 30, 100)
+    with pytest.raises(NotImplementedError):
+        lbm_amd.affine_post(torch.zeros(1, 4, 2000, device=DEV), np.eye(4))
+    assert lbm_amd.affine_post(torch.zeros(0, 4, 100, device=DEV), np.eye(4))["std"].shape == (0, 4, 100)
+    x = synth_epochs(6, 30, 1500, seed=77) * 2.0
+    kw = synth_ica(30)
+    A, b = lbm_amd.ica_projection(**kw)
+    out = lbm_amd.affine_post(x.to(DEV), A, b, n_baseline=251, standardize=True)
+    want, _ = orc.welch_psd(orc.baseline_correct(orc.ica_apply(x.numpy().astype(np.float64), **kw), 251), 500.0, 4.0, 30.0, n_fft=500,
+                            n_overlap=250, window="hann")
+    got, _ = lbm_amd.psd_array_welch(out["std"], 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann", row_scale=out["row_scale"])
+    assert _psd_err(got.cpu().numpy(), want) <= 1.0
+    # generic (non-folded) Welch kernel and per-segment output take the scale too
+    got2, _ = lbm_amd.psd_array_welch(out["std"], 500.0, 4.0, 30.0, n_fft=500, n_overlap=250, window="hann", average=None,
+                                      row_scale=out["row_scale"])
+    want2, _ = orc.welch_psd(orc.baseline_correct(orc.ica_apply(x.numpy().astype(np.float64), **kw), 251), 500.0, 4.0, 30.0, n_fft=500,
+                             n_overlap=250, window="hann", average=None)
+    assert _psd_err(got2.cpu().numpy().reshape(6, 30, -1), want2.reshape(6, 30, -1)) <= 1.0
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_pipeline_fused_and_separate_dsp_fronts_agree(shipped, fuse):
+    """PipelineConfig.fuse_post: both DSP fronts against the oracle, and against each other at fp32 rounding."""
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fuse_post=fuse), taps, A, b, shipped, shipped["vq_layer.embedding.weight"])
+    assert pipe.fused == fuse
+    x = synth_epochs(8, 30, 1500, seed=19) * 2.0
+    x[6, 2, 900] -= 1e-2
+    out = pipe.run(x.to(DEV))
+    want = orc.pipeline(x.numpy(), 500.0, taps, A, b, 251, 150e-6, shipped)
+    assert _rms_ok(out["cleaned"].cpu().numpy(), want["filtered"]) <= 2e-5
+    assert np.array_equal(out["keep"].cpu().numpy().astype(bool), want["keep"])
+    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= PIPELINE_PSD_TOL
+    assert float(np.abs(out["standardized"].cpu().numpy() - want["standardized"]).max()) <= 1e-4
+    assert (out["tokens"].cpu().numpy() == want["tokens"]).mean() >= 0.95
 
 
 # ------------------------------------------------------------------------------------------------ a12-a14 VQ
@@ -625,7 +710,7 @@ def test_pipeline_matches_oracle(shipped, T):
     want = orc.pipeline(x.numpy(), 500.0, taps, A, b, 251, 150e-6, shipped)
     assert _rms_ok(out["cleaned"].cpu().numpy(), want["filtered"]) <= 2e-5
     assert np.array_equal(out["keep"].cpu().numpy().astype(bool), want["keep"])
-    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= 4.0   # three chained fp32 stages feed this PSD
+    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= PIPELINE_PSD_TOL
     np.testing.assert_allclose(out["bandpower"].cpu().numpy(), want["bandpower"], rtol=2e-6)
     assert float(np.abs(out["standardized"].cpu().numpy() - want["standardized"]).max()) <= 1e-4
     tok = out["tokens"].cpu().numpy()
@@ -699,8 +784,11 @@ def test_pipeline_features_only_no_tokenizer(shipped):
     ref = {k: v.clone() for k, v in pipe.run(xd).items()}
     out = pipe2.run(xd)
     assert "tokens" not in out and "hist" not in out and "standardized" not in out
-    for k in ("psd", "bandpower", "keep", "cleaned"):
+    for k in ("keep", "cleaned"):
         assert torch.equal(out[k], ref[k]), k
+    # the full pipeline takes the PSD from the z-scored epochs and the per-row scale, this branch from the cleaned epochs
+    assert _psd_err(out["psd"].cpu().numpy(), ref["psd"].cpu().numpy().astype(np.float64)) <= 0.2
+    np.testing.assert_allclose(out["bandpower"].cpu().numpy(), ref["bandpower"].cpu().numpy(), rtol=2e-6)
     cfg3 = lbm_amd.PipelineConfig(do_tokenize=False, do_filter=False, do_ica=False, emit_cleaned=False)
     out3 = lbm_amd.EpochPipeline(cfg3, None, None, None, None, None).run(xd)
     assert set(out3) == {"psd", "bandpower", "keep"}
@@ -770,7 +858,7 @@ def test_pipeline_config_L_matches_oracle():
     assert _rms_ok(out["cleaned"].cpu().numpy(), want["filtered"]) <= 2e-5
     assert np.array_equal(out["keep"].cpu().numpy().astype(bool), want["keep"])
     assert out["psd"].shape == (2, C, 27)
-    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= 4.0
+    assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= PIPELINE_PSD_TOL
     np.testing.assert_allclose(out["bandpower"].cpu().numpy(), want["bandpower"], rtol=2e-6)
     tok = out["tokens"].cpu().numpy()
     assert tok.shape == want["tokens"].shape == (2, 2500)

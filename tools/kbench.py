@@ -66,7 +66,7 @@ def main():
         ws = torch.empty(lib2.lbm_ica_stats_workspace_bytes(Tr, n), dtype=torch.uint8, device=dev)
         zz = src.contiguous()
         fn = lambda: lib2.lbm_ica_stats_f32(p(zz), Tr, Tr, n, p(Wd), 0, 1.0, p(out), p(out[n * n:]), p(ws), st)  # noqa: E731
-    elif s in ("fir", "fir_direct", "affine", "post", "welch"):
+    elif s in ("fir", "fir_direct", "affine", "post", "welch", "affine_post", "welch_scaled"):
         x = synth_epochs(E, C, T, seed=3, device=dev, chunk=2048)
         y = torch.empty_like(x)
     if s in ("ica_stats",):
@@ -110,6 +110,20 @@ def main():
         A = torch.as_tensor(A).to(dev, torch.float32).contiguous()
         b = torch.as_tensor(b).to(dev, torch.float32).contiguous()
         fn = lambda: lib.lbm_affine_ch_f32(p(x), p(y), E, C, C, T, p(A), p(b), st)  # noqa: E731
+    elif s == "affine_post":
+        A, b = lbm_amd.ica_projection(**synth_ica(C))
+        A = torch.as_tensor(A).to(dev, torch.float32).contiguous()
+        b = torch.as_tensor(b).to(dev, torch.float32).contiguous()
+        keep = torch.empty(E, dtype=torch.uint8, device=dev)
+        rs_ = torch.empty(E, C, device=dev)
+        fn = lambda: lib.lbm_affine_post_f32(p(x), p(A), p(b), None, p(y), p(rs_), p(keep), E, C, C, T, 251, 150e-6, 1, 1e-6, st)  # noqa: E731
+    elif s == "welch_scaled":
+        from lbm_amd.psd import welch_bins, welch_tables
+        _, lo, hi = welch_bins(500.0, 500, 4.0, 30.0)
+        tab = welch_tables(dev, 500, 500, "hann", lo, hi)
+        psd = torch.empty(E, C, hi - lo + 1, device=dev)
+        rs_ = torch.rand(E, C, device=dev) + 0.5
+        fn = lambda: lib.lbm_welch_scaled_f32(p(x), p(rs_), p(psd), None, E * C, T, 500.0, 500, 500, 250, p(tab), lo, hi, 0, st)  # noqa: E731
     elif s == "post":
         y2 = torch.empty_like(x)
         keep = torch.empty(E, dtype=torch.uint8, device=dev)
