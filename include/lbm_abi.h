@@ -107,8 +107,10 @@ int lbm_epochs_gather_f32(const float* raw, int64_t ldr, const int64_t* starts, 
  * transformed, cut (or extended) to round(ratio * N) bins with MNE's Nyquist-bin rule, transformed back and
  * trimmed to lbm_resample_length(T, up, down) = round(T * up / down) samples (round-half-even).
  * x: [rows, T] with pitch ldx; y: [rows, length] with pitch ldy; workspace: lbm_resample_workspace_bytes bytes.
- * Supported ratios: up/down = 2^s (the resampled padded length must stay a power of two); others return
- * LBM_EUNSUPPORTED (workspace_bytes / length return 0).  rows <= 65535 per call. */
+ * Any ratio: when the resampled padded length round(ratio * N) is a power of two (up/down = 2^s) the inverse transform is a
+ * plain FFT; for every other length (250/600, 250/512, 256/500 ...) it is computed as a chirp-z (Bluestein) convolution of the
+ * next power of two >= 2 * length - 1, chirp phases from n^2 mod 2L in exact integer arithmetic.  rows <= 65535 per call;
+ * rows shorter than 16 padded samples return LBM_EUNSUPPORTED (workspace_bytes / length return 0). */
 int64_t lbm_resample_length(int64_t T, int32_t up, int32_t down);
 size_t lbm_resample_workspace_bytes(int64_t rows, int64_t T, int32_t up, int32_t down);
 int lbm_resample_fft_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t T, int32_t up,

@@ -9,7 +9,7 @@ from .constants import *  # noqa: F401,F403
 from . import _lib  # noqa: F401
 from .filter import create_filter, filter_data, notch_filter, fir_apply, resample  # noqa: F401
 from .ica import ica_apply, ica_get_sources, ica_projection, affine_channels, average_reference_matrix  # noqa: F401
-from .fastica import ica_fit, find_bads_eog, fastica_parallel, ica_stats, channel_moments  # noqa: F401
+from .fastica import ica_fit, find_bads_eog, find_bads_ecg, fastica_parallel, ica_stats, channel_moments  # noqa: F401
 from .epochs import (epoch_post, affine_post, affine_post_supported, standardize_epochs, Scaler, n_baseline_samples, make_epochs,  # noqa: F401
                      save_preprocess_outputs, save_withpsd_outputs)
 from .psd import psd_array_welch, band_powers, classify_eeg_state, classify_eeg_state_variant  # noqa: F401

@@ -14,6 +14,7 @@ namespace {
 
 struct Plan {
     int64_t T, N, Nn, final_len, pad0, rem0;   // input, padded, resampled padded, output length; left pad; left trim
+    int64_t M;                                 // 0: Nn is a power of two (plain inverse FFT); else the chirp-z convolution length
     int ok;
 };
 
@@ -35,9 +36,14 @@ Plan make_plan(int64_t T, int up, int down) {
     p.Nn = (int64_t)llrint(ratio * (double)N);
     if (p.Nn < 1) p.Nn = 1;
     p.rem0 = (int64_t)llrint(ratio * (double)p.pad0);
-    const bool pow2 = (p.Nn & (p.Nn - 1)) == 0;
-    p.ok = pow2 && p.Nn >= 16 && N >= 16 && p.final_len >= 1 && N <= (1LL << 30) && p.Nn <= (1LL << 30) &&
-           p.rem0 + p.final_len <= p.Nn;
+    const bool pow2 = (p.Nn & (p.Nn - 1)) == 0 && p.Nn >= 16;
+    p.M = 0;
+    if (!pow2) {   // any other length: the inverse transform of length Nn as a chirp-z (Bluestein) convolution of length M = 2^m >= 2 Nn - 1
+        int64_t M = 16;
+        while (M < 2 * p.Nn - 1) M <<= 1;
+        p.M = M;
+    }
+    p.ok = N >= 16 && p.final_len >= 1 && N <= (1LL << 30) && p.Nn <= (1LL << 29) && p.rem0 + p.final_len <= p.Nn;
     return p;
 }
 
@@ -131,6 +137,69 @@ __global__ __launch_bounds__(256) void resample_trim_kernel(const float2* __rest
     y[(int64_t)blockIdx.y * ldy + i] = z[(int64_t)blockIdx.y * Nn + rem0 + i].x * scale;
 }
 
+// ---- inverse transform of arbitrary length L = Nn as a chirp-z convolution (Bluestein):
+//   y[n] = sum_k Z[k] e^{+2 pi i n k / L} = c[n] * sum_k (Z[k] c[k]) conj(c[n - k]),   c[n] = e^{i pi n^2 / L}
+// chirp[n] for n < L (phase from n^2 mod 2L in exact integer arithmetic, evaluated in float64, rounded once) and the wrapped
+// kernel b[m] = conj(c[m]) at m and M - m, zero elsewhere
+__global__ __launch_bounds__(256) void chirp_kernel(float2* __restrict__ chirp, float2* __restrict__ b, int64_t L, int64_t M) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float2 bv = make_float2(0.f, 0.f);
+    const int64_t n = m < L ? m : (M - m < L ? M - m : -1);
+    if (n >= 0) {
+        const int64_t q = (int64_t)(((unsigned long long)n * (unsigned long long)n) % (unsigned long long)(2 * L));   // n < 2^29: n^2 < 2^58
+        double sn, cs;
+        sincospi((double)q / (double)L, &sn, &cs);
+        bv = make_float2((float)cs, -(float)sn);
+        if (m < L) chirp[m] = make_float2((float)cs, (float)sn);
+    }
+    b[m] = bv;
+}
+
+// A[k] = Z[k] c[k] for k < L (Z = the Hermitian spectrum resample_spectrum_kernel builds), 0 up to M
+__global__ __launch_bounds__(256) void chirp_premul_kernel(const float2* __restrict__ X, float2* __restrict__ A, const float2* __restrict__ chirp,
+                                                           int64_t N, int64_t L, int64_t M) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= M) return;
+    float2 v = make_float2(0.f, 0.f);
+    if (k < L) {
+        const float2* xr = X + (int64_t)blockIdx.y * N;
+        const bool shorter = L < N;
+        const int64_t use = shorter ? L : N;
+        const int64_t half = use / 2;
+        const int64_t kk = k <= L / 2 ? k : L - k;
+        if (kk <= half) {
+            v = xr[kk];
+            if (kk == half && (use % 2 == 0)) {
+                const float f = shorter ? 2.f : 0.5f;
+                v.x *= f;
+                v.y *= f;
+            }
+            if (kk == 0 || (kk == L / 2 && L % 2 == 0)) v.y = 0.f;
+            if (k > L / 2) v.y = -v.y;
+        }
+        const float2 c = chirp[k];
+        v = make_float2(v.x * c.x - v.y * c.y, v.x * c.y + v.y * c.x);
+    }
+    A[(int64_t)blockIdx.y * M + k] = v;
+}
+
+__global__ __launch_bounds__(256) void pointwise_mul_kernel(float2* __restrict__ a, const float2* __restrict__ fb, int64_t M) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= M) return;
+    float2* p = a + (int64_t)blockIdx.y * M + k;
+    const float2 v = *p, w = fb[k];
+    *p = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+}
+
+__global__ __launch_bounds__(256) void chirp_trim_kernel(const float2* __restrict__ z, const float2* __restrict__ chirp, float* __restrict__ y,
+                                                         int64_t ldy, int64_t M, int64_t rem0, int64_t final_len, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= final_len) return;
+    const float2 v = z[(int64_t)blockIdx.y * M + rem0 + i], c = chirp[rem0 + i];
+    y[(int64_t)blockIdx.y * ldy + i] = (v.x * c.x - v.y * c.y) * scale;
+}
+
 template <bool INV>
 int run_fft(float2*& cur, float2*& other, int64_t N, int64_t rows, hipStream_t st) {
     int64_t Ns = 1;
@@ -162,8 +231,12 @@ extern "C" int64_t lbm_resample_length(int64_t T, int32_t up, int32_t down) {
 extern "C" size_t lbm_resample_workspace_bytes(int64_t rows, int64_t T, int32_t up, int32_t down) {
     const Plan p = make_plan(T, up, down);
     if (!p.ok || rows < 1) return 0;
-    const int64_t big = p.N > p.Nn ? p.N : p.Nn;
-    return (size_t)rows * (size_t)big * sizeof(float2) * 2;
+    if (p.M == 0) {
+        const int64_t big = p.N > p.Nn ? p.N : p.Nn;
+        return (size_t)rows * (size_t)big * sizeof(float2) * 2;
+    }
+    const int64_t big = p.N > p.M ? p.N : p.M;
+    return ((size_t)rows * (size_t)big * 2 + (size_t)(2 * p.M + p.Nn)) * sizeof(float2);   // + kernel spectrum ping-pong + chirp
 }
 
 extern "C" int lbm_resample_fft_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int64_t T, int32_t up,
@@ -173,12 +246,48 @@ extern "C" int lbm_resample_fft_f32(const float* x, int64_t ldx, float* y, int64
     LBM_REQUIRE(x && y && workspace, LBM_EINVAL, "lbm_resample_fft_f32: NULL pointer");
     LBM_REQUIRE(rows <= 65535, LBM_EUNSUPPORTED, "lbm_resample_fft_f32: at most 65535 rows per call");
     const Plan p = make_plan(T, up, down);
-    LBM_REQUIRE(p.ok, LBM_EUNSUPPORTED,
-                "lbm_resample_fft_f32: ratio %d/%d of a %lld-sample row is not supported (the resampled padded length must be a "
-                "power of two: ratios 2^s)", up, down, (long long)T);
+    LBM_REQUIRE(p.ok, LBM_EUNSUPPORTED, "lbm_resample_fft_f32: ratio %d/%d of a %lld-sample row is not supported (row too short or too long)",
+                up, down, (long long)T);
     LBM_REQUIRE(ldx >= T && ldy >= p.final_len, LBM_EINVAL, "lbm_resample_fft_f32: row pitch shorter than the row");
     LBM_REQUIRE(((uintptr_t)workspace & 7) == 0, LBM_EINVAL, "lbm_resample_fft_f32: workspace must be 8-byte aligned");
     hipStream_t st = lbm::as_stream(stream);
+    if (p.M != 0) {
+        // resampled padded length is not a power of two: forward FFT as below, inverse by chirp-z convolution
+        const int64_t big = p.N > p.M ? p.N : p.M;
+        float2* a = static_cast<float2*>(workspace);
+        float2* b = a + rows * big;
+        float2* kb0 = b + rows * big;          // [M] convolution kernel / its spectrum (ping-pong with kb1)
+        float2* kb1 = kb0 + p.M;
+        float2* chirp = kb1 + p.M;             // [Nn]
+        hipLaunchKernelGGL(chirp_kernel, dim3((unsigned)((p.M + 255) / 256)), dim3(256), 0, st, chirp, kb0, p.Nn, p.M);
+        int rc = lbm::check_launch("lbm_resample_fft_f32(chirp)");
+        if (rc != LBM_OK) return rc;
+        float2 *kc = kb0, *ko = kb1;
+        rc = run_fft<false>(kc, ko, p.M, 1, st);
+        if (rc != LBM_OK) return rc;
+        hipLaunchKernelGGL(resample_pad_kernel, dim3((unsigned)((p.N + 255) / 256), (unsigned)rows), dim3(256), 0, st, x, ldx, a, T, p.N, p.pad0);
+        rc = lbm::check_launch("lbm_resample_fft_f32(pad)");
+        if (rc != LBM_OK) return rc;
+        float2 *cur = a, *other = b;
+        rc = run_fft<false>(cur, other, p.N, rows, st);
+        if (rc != LBM_OK) return rc;
+        hipLaunchKernelGGL(chirp_premul_kernel, dim3((unsigned)((p.M + 255) / 256), (unsigned)rows), dim3(256), 0, st, cur, other, chirp, p.N,
+                           p.Nn, p.M);
+        rc = lbm::check_launch("lbm_resample_fft_f32(premul)");
+        if (rc != LBM_OK) return rc;
+        { float2* t = cur; cur = other; other = t; }
+        rc = run_fft<false>(cur, other, p.M, rows, st);
+        if (rc != LBM_OK) return rc;
+        hipLaunchKernelGGL(pointwise_mul_kernel, dim3((unsigned)((p.M + 255) / 256), (unsigned)rows), dim3(256), 0, st, cur, kc, p.M);
+        rc = lbm::check_launch("lbm_resample_fft_f32(mul)");
+        if (rc != LBM_OK) return rc;
+        rc = run_fft<true>(cur, other, p.M, rows, st);
+        if (rc != LBM_OK) return rc;
+        // 1/M of the convolution's inverse FFT, and irfft's 1/new_len times MNE's ratio new_len / orig_len = 1 / N
+        hipLaunchKernelGGL(chirp_trim_kernel, dim3((unsigned)((p.final_len + 255) / 256), (unsigned)rows), dim3(256), 0, st, cur, chirp, y, ldy,
+                           p.M, p.rem0, p.final_len, (float)(1.0 / ((double)p.N * (double)p.M)));
+        return lbm::check_launch("lbm_resample_fft_f32(trim)");
+    }
     const int64_t big = p.N > p.Nn ? p.N : p.Nn;
     float2* a = static_cast<float2*>(workspace);
     float2* b = a + rows * big;

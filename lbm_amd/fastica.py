@@ -206,23 +206,24 @@ def _find_outliers(X: np.ndarray, threshold: float = 3.0, max_iter: int = 2) -> 
     return np.where(mask)[0]
 
 
-def find_bads_eog(ica: dict, data, eog, sfreq: float, *, threshold: float = 3.0, l_freq: float = 1.0, h_freq: float = 10.0):
-    """Components whose 1-10 Hz time course correlates with the (1-10 Hz) EOG signal: Pearson scores, iterative
-    z-score outliers above ``threshold``, ordered by |score| (``ICA.find_bads_eog(measure='zscore')``).
-
-    ``data``: the ``[C, T]`` recording the ICA was fitted on; ``eog``: ``[T]`` signal of the EOG (or frontal) channel.
-    Returns ``(indices list, scores [n])``.
-    """
+def _find_bads_ch(ica: dict, data, target, sfreq: float, threshold: float, l_freq: float, h_freq: float):
+    """``ICA._find_bads_ch`` with ``measure='zscore'``: Pearson correlation of the band-passed component time courses with the
+    band-passed target channel (``score_sources(score_func='pearsonr', l_freq, h_freq)``), iterative z-score outliers above
+    ``threshold``, ordered by |score|.  The sources, the band-pass and the moments all run on the GPU (affine map, FIR,
+    second-moment pass); the n-vector of scores is host work."""
     from .filter import filter_data
     x = _lib.dev_f32(data)
     A, b = ica_sources_matrix(unmixing=ica["unmixing"], pca_components=ica["pca_components"], pca_mean=ica["pca_mean"],
                               pre_whitener=ica["pre_whitener"], n_components=ica["n_components"])
     n = A.shape[0]
     if n + 1 > 64:
-        raise ValueError("find_bads_eog: at most 63 components")
+        raise ValueError("component scoring: at most 63 components")
+    tgt = _lib.dev_f32(target).reshape(-1)
+    if tgt.numel() != x.shape[1]:
+        raise ValueError(f"target channel has {tgt.numel()} samples, the recording {x.shape[1]}")
     stack = torch.empty((n + 1, x.shape[1]), dtype=torch.float32, device=x.device)
     stack[:n] = affine_channels(x, A, b)
-    stack[n] = _lib.dev_f32(eog).reshape(-1)
+    stack[n] = tgt
     stack = filter_data(stack, sfreq, l_freq, h_freq)
     s1, s2 = channel_moments(stack)
     T = stack.shape[1]
@@ -233,3 +234,32 @@ def find_bads_eog(ica: dict, data, eog, sfreq: float, *, threshold: float = 3.0,
     bad = _find_outliers(scores, threshold=threshold)
     bad = bad[np.argsort(np.abs(scores[bad]))[::-1]]
     return [int(i) for i in bad], scores
+
+
+def find_bads_eog(ica: dict, data, eog, sfreq: float, *, threshold: float = 3.0, l_freq: float = 1.0, h_freq: float = 10.0):
+    """Components whose 1-10 Hz time course correlates with the (1-10 Hz) EOG signal: Pearson scores, iterative
+    z-score outliers above ``threshold``, ordered by |score| (``ICA.find_bads_eog(measure='zscore')``,
+    training/preprocess.py:108, multi-train/withpsd.py:136-139).
+
+    ``data``: the ``[C, T]`` recording the ICA was fitted on; ``eog``: ``[T]`` signal of the EOG (or frontal) channel.
+    Returns ``(indices list, scores [n])``.
+    """
+    return _find_bads_ch(ica, data, eog, sfreq, threshold, l_freq, h_freq)
+
+
+def find_bads_ecg(ica: dict, data, ecg, sfreq: float, *, method: str = "correlation", threshold="auto", l_freq: float = 8.0,
+                  h_freq: float = 16.0, measure: str = "zscore"):
+    """``ica.find_bads_ecg(raw, ch_name=ecg, method='correlation', threshold='auto')`` (multi-train/withpsd.py:145, also
+    multi-train/preprocessv2.py:161): components whose 8-16 Hz time course correlates with the 8-16 Hz ECG channel; with
+    ``threshold='auto'`` and the z-score measure the outlier threshold is 3.0 (MNE 1.5 ``find_bads_ecg``).  MNE's default
+    ``method='ctps'`` (cross-trial phase statistics over detected heart beats) is not what the reference calls and is not
+    implemented.
+
+    ``ecg``: the ``[T]`` signal of the ECG channel.  Returns ``(indices list, scores [n])``.
+    """
+    if method != "correlation":
+        raise NotImplementedError("find_bads_ecg: only method='correlation' (the reference's call) is implemented")
+    if measure != "zscore":
+        raise NotImplementedError("find_bads_ecg: only measure='zscore' (MNE's default) is implemented")
+    thr = 3.0 if threshold == "auto" else float(threshold)
+    return _find_bads_ch(ica, data, ecg, sfreq, thr, l_freq, h_freq)

@@ -175,7 +175,8 @@ def notch_filter(data, sfreq, freqs, *, notch_widths=None, trans_bandwidth=1.0, 
 def resample(data, up: int = 1, down: int = 1):
     """``mne.filter.resample(data, up, down, npad='auto', window='boxcar', pad='reflect_limited')`` along the last axis
     (``raw.resample(250)`` at preprocessing_unsupervised.py:37 is ``resample(data, 250, 500)`` after reduction).
-    Ratios 2^s only (see ``lbm_resample_fft_f32``)."""
+    Any ratio: power-of-two resampled lengths by plain FFTs, every other length by a chirp-z inverse transform
+    (see ``lbm_resample_fft_f32``)."""
     from math import gcd
     up, down = int(up), int(down)
     g = gcd(up, down)
@@ -188,7 +189,7 @@ def resample(data, up: int = 1, down: int = 1):
     n_out = lib.lbm_resample_length(T, up, down)
     nbytes = lib.lbm_resample_workspace_bytes(min(rows, 64), T, up, down) if rows else 0
     if T and (n_out == 0 or nbytes == 0):
-        raise NotImplementedError(f"resample: ratio {up}/{down} of {T} samples is not supported (ratios 2^s only)")
+        raise NotImplementedError(f"resample: ratio {up}/{down} of {T} samples is not supported (row too short or too long)")
     x2 = x.reshape(rows, T)
     y = torch.empty((rows, n_out), dtype=torch.float32, device=x.device)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)

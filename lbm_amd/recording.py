@@ -175,12 +175,13 @@ def preprocess_recording(data, sfreq: float, annotations, *, l_freq: float = FIL
 
 def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: float = FILTER_LFREQ, h_freq: float = FILTER_HFREQ,
                                  notch: Optional[float] = NOTCH_FREQ, ica: bool = True, n_components=ICA_N_COMPONENTS,
-                                 random_state=ICA_RANDOM_STATE, ica_fit_params=None, eog=None, exclude: Sequence[int] = (),
+                                 random_state=ICA_RANDOM_STATE, ica_fit_params=None, eog=None, ecg=None, exclude: Sequence[int] = (),
                                  tmin: float = TMIN, tmax: float = TMAX, rt_filter: float = RT_FILTER_THRESHOLD,
                                  reject: Optional[float] = 150e-6, psd_fmin: float = FILTER_LFREQ, psd_fmax: float = FILTER_HFREQ,
                                  psd_window: str = "hann") -> dict:
     """The per-file body of multi-train/withpsd.py (:96-283) on one continuous ``[C, T]`` recording: filter -> notch ->
-    ICA fit/apply -> trials (10th-percentile baseline, :192) -> stimulus-locked epochs (:204) with baseline and
+    ICA fit, EOG scoring (``eog``: the [T] signal of an EOG / frontal channel, :136-139) and ECG scoring (``ecg``: the [T] signal of
+    the ECG channel, ``find_bads_ecg(method='correlation', threshold='auto')``, :145), apply -> trials (10th-percentile baseline, :192) -> stimulus-locked epochs (:204) with baseline and
     peak-to-peak rejection (:213-219) -> Welch PSD per epoch (:236-250, n_fft = int(sfreq), half overlap, Hann) ->
     ``Scaler(scalings='mean')`` over the kept epochs (:267-270).
 
@@ -189,7 +190,7 @@ def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: flo
     """
     from . import _lib
     from .epochs import Scaler, epoch_post, make_epochs, n_baseline_samples
-    from .fastica import find_bads_eog, ica_fit
+    from .fastica import find_bads_ecg, find_bads_eog, ica_fit
     from .filter import filter_data, notch_filter
     from .ica import ica_apply
     from .psd import psd_array_welch
@@ -206,6 +207,9 @@ def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: flo
         bad = [int(i) for i in exclude]
         if eog is not None:
             idx, _ = find_bads_eog(state, x, eog, sfreq)                               # :136-139 (default threshold)
+            bad.extend(idx)
+        if ecg is not None:
+            idx, _ = find_bads_ecg(state, x, ecg, sfreq, method="correlation", threshold="auto")       # :145
             bad.extend(idx)
         state["exclude"] = sorted(set(bad))
         keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")

@@ -415,6 +415,14 @@ def find_bads_eog(ica: dict, data, eog, sfreq, threshold=3.0, l_freq=1.0, h_freq
     return [int(i) for i in bad], scores
 
 
+def find_bads_ecg(ica: dict, data, ecg, sfreq, threshold="auto", l_freq=8.0, h_freq=16.0):
+    """``ica.find_bads_ecg(raw, ch_name, method='correlation', threshold='auto')`` (multi-train/withpsd.py:145): MNE 1.5 routes
+    the correlation method through the same ``_find_bads_ch`` as the EOG scoring, with the 8-16 Hz band and, for
+    threshold='auto' with the z-score measure, a threshold of 3.0.  Restated from MNE (parity unpinned)."""
+    thr = 3.0 if threshold == "auto" else float(threshold)
+    return find_bads_eog(ica, data, ecg, sfreq, threshold=thr, l_freq=l_freq, h_freq=h_freq)
+
+
 # --------------------------------------------------------------------------------------
 # 8(f)-4: annotations -> trials -> vigilance labels (training/preprocess.py:156-259), line-by-line semantics
 # --------------------------------------------------------------------------------------

@@ -110,6 +110,41 @@ def test_find_bads_eog_matches_oracle():
     assert np.abs(scores - want_scores).max() <= 2e-3
 
 
+def test_find_bads_ecg_correlation_matches_oracle():
+    """ica.find_bads_ecg(..., method='correlation', threshold='auto') (multi-train/withpsd.py:145): a cardiac artefact (QRS-like
+    spikes at ~1.1 Hz, energy in the 8-16 Hz scoring band) leaked into the channels must be found, with the oracle's scores."""
+    rng = np.random.RandomState(9)
+    C, T, fs = 14, 60000, 500.0
+    x, _ = _mixture(C, T, seed=9)
+    beat = np.zeros(T)
+    t = 200
+    while t < T - 100:
+        beat[t:t + 40] += np.hanning(40) * np.sin(np.linspace(0, 3 * np.pi, 40))      # a 80 ms QRS-like wavelet
+        t += int(fs * (0.9 + 0.1 * rng.rand()))
+    topo = rng.randn(C) * 0.5
+    x = x + 6e-5 * topo[:, None] * beat[None, :]
+    ecg = 1e-3 * beat + 5e-6 * rng.randn(T)
+    ref = orc.ica_fit(x)
+    want_idx, want_scores = orc.find_bads_ecg(ref, x, ecg, fs)
+    xd = torch.from_numpy(x).to(DEV, torch.float32)
+    got = lbm_amd.ica_fit(xd)
+    idx, scores = lbm_amd.find_bads_ecg(got, xd, torch.from_numpy(ecg).to(DEV, torch.float32), fs, method="correlation", threshold="auto")
+    assert len(want_idx) >= 1, "the synthetic cardiac component must be detectable"
+    assert idx == want_idx
+    assert np.abs(scores - want_scores).max() <= 2e-3
+    # an explicit threshold is taken as given; MNE's default method is refused, not silently replaced
+    idx9, _ = lbm_amd.find_bads_ecg(got, xd, torch.from_numpy(ecg).to(DEV, torch.float32), fs, threshold=9.0)
+    assert set(idx9) <= set(idx)
+    with pytest.raises(NotImplementedError):
+        lbm_amd.find_bads_ecg(got, xd, ecg, fs, method="ctps")
+    # the per-file driver of multi-train/withpsd.py excludes what the ECG scoring finds
+    ann = [(10.0 + 6.0 * i, "251") for i in range(15)] + [(10.6 + 6.0 * i, "253") for i in range(15)]
+    ann.sort()
+    out = lbm_amd.preprocess_recording_withpsd(x, fs, ann, ecg=ecg, notch=None)
+    out0 = lbm_amd.preprocess_recording_withpsd(x, fs, ann, notch=None)
+    assert len(out["ica"]["exclude"]) >= 1 and out0["ica"]["exclude"] == []
+
+
 def test_preprocess_recording_matches_oracle_flow():
     """training/preprocess.py end to end on a synthetic continuous recording: filter -> notch -> ICA fit -> apply ->
     trials / labels -> epochs -> baseline -> z-score, GPU stages vs the oracle's float64 restatement of each."""

@@ -984,7 +984,10 @@ def test_vq_full_size_every_row_is_a_minimum(shipped):
 @pytest.mark.parametrize("T,up,down,rows", [(5000, 1, 2, 3), (1001, 1, 2, 2), (30000, 250, 1000, 2), (65539, 250, 500, 1), (3000, 2, 1, 2),
                                             (70, 1, 2, 1), (300000, 1, 2, 70),
                                             (2 ** 17 - 300, 1, 2, 2),     # T + min_add <= 2^17 < T + 2 min_add: MNE pads to 2^17
-                                            (2 ** 12 - 150, 1, 2, 1)])
+                                            (2 ** 12 - 150, 1, 2, 1),
+                                            # resampled padded length not a power of two: chirp-z inverse transform
+                                            (30000, 250, 600, 2), (4000, 250, 512, 3), (5000, 256, 500, 1), (3000, 3, 2, 2),
+                                            (100000, 250, 1024, 2), (333, 7, 5, 1), (20, 1, 3, 1)])
 def test_resample_matches_oracle(T, up, down, rows):
     """raw.resample (preprocessing_unsupervised.py:37): FFT resampling with MNE's auto padding, vs the float64 oracle."""
     rs = np.random.RandomState(T)
@@ -1003,7 +1006,8 @@ def test_resample_matches_oracle(T, up, down, rows):
 
 def test_resample_unsupported_ratio_and_empty():
     with pytest.raises(NotImplementedError):
-        lbm_amd.resample(torch.zeros(2, 1000, device=DEV), 250, 512)
+        lbm_amd.resample(torch.zeros(2, 3, device=DEV), 1, 2)            # fewer than 16 padded samples
+    assert lbm_amd.resample(torch.zeros(2, 1000, device=DEV), 250, 512).shape == (2, 488)   # round(1000 * 250 / 512)
     lib = _lib.load()
     assert lib.lbm_resample_length(1001, 1, 2) == 500 and lib.lbm_resample_length(1003, 1, 2) == 502      # round-half-even
     assert lib.lbm_resample_fft_f32(None, 0, None, 0, 0, 100, 1, 2, None, None) == 0

@@ -197,3 +197,24 @@ def test_resample_oracle_band_limited_signal_and_lengths():
     assert orc.resample(np.zeros((1, 1003)), 1, 2).shape == (1, 502)
     up = orc.resample(x[None, :1000], 2, 1)[0]
     assert up.shape == (2000,) and np.abs(up[::2][50:-50] - x[:1000][50:-50]).max() < 2e-3
+
+
+def test_oracle_resample_core_equals_scipy_signal_resample():
+    """The oracle's FFT resampler (MNE's mne.filter.resample restated: npad='auto' padding by odd reflection, spectrum cut with
+    the Nyquist-bin rule, trim) against scipy.signal.resample applied to the same padded rows -- pins everything but the padding
+    rule itself (parity unpinned at the MNE boundary) for power-of-two and other resampled lengths."""
+    from scipy.signal import resample as sresample
+    rs = np.random.RandomState(0)
+    for T, up, down in [(3000, 250, 600), (4000, 250, 512), (1000, 1, 2), (3000, 3, 2), (2 ** 12 - 150, 1, 2)]:
+        x = rs.randn(2, T).cumsum(1)
+        y = orc.resample(x, up, down)
+        min_add = min(T // 8, 100) * 2
+        npad = 2 ** int(np.ceil(np.log2(T + min_add))) - T          # mne/filter.py resample(npad='auto')
+        n0, n1 = npad // 2, npad - npad // 2
+        ratio = up / down
+        for r, got in zip(x, y):
+            pad = np.concatenate([orc._reflect_limited_side(r, n0, True), r, orc._reflect_limited_side(r, n1, False)])
+            z = sresample(pad, int(round(ratio * len(pad))))
+            rem0, fl = int(round(ratio * n0)), int(round(ratio * T))
+            assert got.shape == (fl,)
+            assert np.abs(got - z[rem0:rem0 + fl]).max() <= 1e-12 * np.abs(z).max()
