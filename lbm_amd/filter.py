@@ -154,15 +154,37 @@ def filter_data(data, sfreq, l_freq, h_freq, *, l_trans_bandwidth="auto", h_tran
 
 
 def notch_taps(sfreq, freqs, notch_widths=None, trans_bandwidth: float = 1.0, fir_window="hamming"):
+    """The band-stop design of ``mne.filter.notch_filter(method='fir')``: ONE multi-band FIR for all notch frequencies
+    (``filter_data(x, sfreq, l_freq=highs, h_freq=lows, tb_2, tb_2)`` -> ``create_filter`` with array edges: pass edges
+    f -/+ (w/2 + tb/2), stop edges f -/+ w/2, all edges sorted into one gain template).  Returns a one-element list (kept a list:
+    ``notch_filter`` applies every design in it)."""
+    sfreq = float(sfreq)
+    nyq = sfreq / 2.0
     freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
     widths = freqs / 200.0 if notch_widths is None else np.broadcast_to(np.asarray(notch_widths, dtype=np.float64), freqs.shape)
     tb_2 = trans_bandwidth / 2.0
-    return [create_filter(sfreq, f + w / 2.0 + tb_2, f - w / 2.0 - tb_2, tb_2, tb_2, fir_window) for f, w in zip(freqs, widths)]
+    f_p1, f_p2 = freqs - widths / 2.0 - tb_2, freqs + widths / 2.0 + tb_2      # pass edges below / above each notch
+    f_s1, f_s2 = f_p1 + tb_2, f_p2 - tb_2                                        # stop edges
+    edges = np.r_[f_p1, f_s1, f_s2, f_p2]
+    gains = np.r_[np.ones_like(f_p1), np.zeros_like(f_s1), np.zeros_like(f_s2), np.ones_like(f_p2)]
+    if edges.min() <= 0 or edges.max() >= nyq:
+        raise ValueError("notch edges must lie inside (0, sfreq / 2)")
+    order = np.argsort(edges, kind="stable")
+    freq = np.r_[0.0, edges[order], nyq]
+    gain = np.r_[1.0, gains[order], 1.0]
+    if np.any(np.abs(np.diff(gain, 2)) > 1):
+        raise ValueError("Stop bands are not sufficiently separated.")
+    n_taps = int(round(_LENGTH_FACTORS[fir_window] * sfreq / tb_2))
+    n_taps += 1 - n_taps % 2
+    fn = [f / nyq for f in freq]
+    fn[-1] = 1.0
+    return [_compose(n_taps, fn, [int(g) for g in gain], fir_window)]
 
 
 def notch_filter(data, sfreq, freqs, *, notch_widths=None, trans_bandwidth=1.0, fir_design="firwin",
                  fir_window="hamming", pad="reflect_limited"):
-    """``mne.filter.notch_filter`` equivalent: one band-stop FIR per notch frequency, applied in sequence."""
+    """``mne.filter.notch_filter`` equivalent (``raw.notch_filter(freqs=60.0, fir_design='firwin')``, training/preprocess.py:82,
+    multi-train/withpsd.py:119): one multi-band band-stop FIR over all notch frequencies (``notch_taps``)."""
     if fir_design != "firwin":
         raise NotImplementedError("only fir_design='firwin'")
     was_numpy = not isinstance(data, torch.Tensor)

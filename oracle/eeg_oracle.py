@@ -134,20 +134,34 @@ def design_notch(sfreq: float, freqs: Iterable[float] | float, notch_widths=None
                  trans_bandwidth: float = 1.0, fir_window: str = "hamming"):
     """``raw.notch_filter(freqs, fir_design='firwin')`` designs (training/preprocess.py:82).
 
-    Returns one band-stop tap vector per notch frequency (MNE applies them in sequence).
+    MNE calls ``filter_data(x, sfreq, l_freq=highs, h_freq=lows, tb_2, tb_2)`` with ARRAY edges: ``create_filter`` sorts the pass
+    and stop edges of all notches into one template and designs ONE multi-band band-stop filter.  Returned as a one-element list.
     LOWEST-CONFIDENCE item of SURVEY.md App. A1; unverifiable without MNE.
     """
+    sfreq = float(sfreq)
+    nyq = sfreq / 2.0
     freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
     widths = freqs / 200.0 if notch_widths is None else np.broadcast_to(
         np.asarray(notch_widths, dtype=np.float64), freqs.shape)
     tb_2 = trans_bandwidth / 2.0
-    out = []
-    for f, w in zip(freqs, widths):
-        lows = f - w / 2.0 - tb_2
-        highs = f + w / 2.0 + tb_2
-        out.append(design_fir(sfreq, highs, lows, l_trans_bandwidth=tb_2,
-                              h_trans_bandwidth=tb_2, fir_window=fir_window))
-    return out
+    lows = np.array([f - w / 2.0 - tb_2 for f, w in zip(freqs, widths)])
+    highs = np.array([f + w / 2.0 + tb_2 for f, w in zip(freqs, widths)])
+    f_p1, f_s1, f_s2, f_p2 = lows, lows + tb_2, highs - tb_2, highs
+    freq = np.r_[f_p1, f_s1, f_s2, f_p2]
+    gain = np.r_[np.ones_like(f_p1), np.zeros_like(f_s1), np.zeros_like(f_s2), np.ones_like(f_p2)]
+    order = np.argsort(freq, kind="stable")
+    freq = np.r_[0.0, freq[order]]
+    gain = np.r_[1.0, gain[order]]
+    if freq[-1] != nyq:
+        freq = np.r_[freq, nyq]
+        gain = np.r_[gain, 1.0]
+    if np.any(np.abs(np.diff(gain, 2)) > 1):
+        raise ValueError("Stop bands are not sufficiently separated.")
+    n_taps = int(round(_LENGTH_FACTORS[fir_window] * sfreq / tb_2))
+    n_taps += 1 - n_taps % 2
+    fn = [f / nyq for f in freq]
+    fn[-1] = 1.0
+    return [_firwin_design(n_taps, fn, [int(g) for g in gain], fir_window)]
 
 
 def _smart_pad(x: np.ndarray, n_pad: int) -> np.ndarray:

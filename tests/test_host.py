@@ -33,8 +33,12 @@ def test_fir_design_matches_scipy_based_oracle():
     np.testing.assert_allclose(lbm_amd.create_filter(500.0, 1.0, 40.0), orc.design_fir(500.0, 1.0, 40.0), atol=1e-15)
     np.testing.assert_allclose(lbm_amd.create_filter(500.0, None, 30.0), orc.design_fir(500.0, None, 30.0), atol=1e-15)
     np.testing.assert_allclose(lbm_amd.create_filter(500.0, 4.0, None), orc.design_fir(500.0, 4.0, None), atol=1e-15)
-    for a, b in zip(notch_taps(500.0, [60.0, 120.0]), orc.design_notch(500.0, [60.0, 120.0])):
-        np.testing.assert_allclose(a, b, atol=1e-15)
+    for fr in ([60.0, 120.0], 60.0, [50.0, 100.0, 150.0, 200.0]):
+        got, want = notch_taps(500.0, fr), orc.design_notch(500.0, fr)
+        assert len(got) == len(want) == 1                  # one multi-band design, as mne.filter.notch_filter builds
+        np.testing.assert_allclose(got[0], want[0], atol=1e-15)
+    with pytest.raises(ValueError):
+        notch_taps(500.0, [60.0, 60.9])
     with pytest.raises(ValueError):
         lbm_amd.create_filter(500.0, None, None)
 
@@ -118,5 +122,6 @@ def test_argument_validation_without_launch():
     assert b"NULL" in lib.lbm_last_error()
     assert lib.lbm_conv1d_bf16x6_f32(None, 376, None, None, None, 376, 4, 128, 375, 256, 3, 1, 1, 1, None) == -1
     assert lib.lbm_conv1d_bf16x6_f32(None, 376, None, None, None, 376, 0, 128, 375, 256, 3, 1, 1, 1, None) == 0   # empty batch
-    assert lib.lbm_resample_length(1800000, 250, 500) == 900000 and lib.lbm_resample_length(1000, 3, 7) == 0
+    assert lib.lbm_resample_length(1800000, 250, 500) == 900000 and lib.lbm_resample_length(1000, 3, 7) == 429   # any ratio
+    assert lib.lbm_resample_length(3, 1, 2) == 0 and lib.lbm_resample_workspace_bytes(2, 1000, 3, 7) > 2 * 2 * 2048 * 8
     assert lib.lbm_resample_fft_f32(None, 1000, None, 500, 2, 1000, 3, 7, None, None) < 0

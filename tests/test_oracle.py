@@ -87,6 +87,17 @@ def test_fir_design_lengths_and_response():
     (hn,) = orc.design_notch(500.0, 60.0)
     assert len(hn) == 3301
     assert _resp(hn, 60.0, 500.0) < 0.01 and abs(_resp(hn, 20.0, 500.0) - 1) < 1e-3
+    # the single notch is the plain band-stop design with the same edges
+    np.testing.assert_allclose(hn, orc.design_fir(500.0, 60.65, 59.35, l_trans_bandwidth=0.5, h_trans_bandwidth=0.5), atol=1e-15)
+    # several frequencies: ONE multi-band filter (mne.filter.notch_filter hands create_filter array edges), a zero at each
+    (hm,) = orc.design_notch(500.0, [60.0, 120.0, 180.0])
+    assert len(hm) == 3301 and np.allclose(hm, hm[::-1], atol=0)
+    for f in (60.0, 120.0, 180.0):
+        assert _resp(hm, f, 500.0) < 0.01
+    for f in (20.0, 90.0, 150.0, 220.0):
+        assert abs(_resp(hm, f, 500.0) - 1) < 2e-3
+    with pytest.raises(ValueError):
+        orc.design_notch(500.0, [60.0, 60.9])          # stop bands overlap
 
 
 def test_fir_zero_phase_identities():
