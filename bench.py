@@ -243,9 +243,12 @@ def parse_args(argv=None):
                     help="codebook argmin kernel: fp32 MFMA (default) or fp32 products from three bf16 pieces on the bf16 MFMA")
     ap.add_argument("--conv", choices=["fp32", "bf16x6"], default="fp32",
                     help="256-channel encoder layers: fp32 MFMA kernels (default) or the three-bf16-piece implicit GEMM")
-    ap.add_argument("--fold-proj", action="store_true",
-                    help="non-default variant: tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook "
-                         "(PipelineConfig.fold_projection; no z tensor; equal tokens except fp32 near-ties)")
+    ap.add_argument("--no-fold-proj", dest="fold_proj", action="store_false",
+                    help="run the encoder's last 1x1 convolution as its own GEMM and quantise its output z (the layer chain as "
+                         "training/model.py:169-177 writes it).  Default: the layer is folded into the codebook "
+                         "(PipelineConfig.fold_projection, exact fp32 algebra done once on the host; tokens equal except documented "
+                         "fp32 near-ties; z is not among the path's outputs), DESIGN.md section 4")
+    ap.set_defaults(fold_proj=True)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (the measured path); gloo = rehearsal of the N > 1 control flow on a box "
                          "with fewer GPUs than ranks (ranks share devices, collectives staged through host memory)")
@@ -437,6 +440,10 @@ def run_rank(args):
     # room left beside the resident input: allocator slack, RCCL's buffers and (N > 1) the flattened receive buffers torch
     # stages one group of each array through before it scatters them to the [w, lo:hi] slices
     reserve = 6 << 30
+    run_variants = rank == 0 and args.shape == "S" and args.fold_proj and args.vq == "fp32" and args.conv == "fp32"
+    z_var = None
+    if run_variants:      # the unfolded variants write z: take that buffer before the resident input claims the rest of the HBM
+        z_var = torch.empty((chunk, D, pipe.P2), dtype=torch.float32, device=dev)
     if xch is not None:
         reserve += (2 << 30) + 3 * world * ((E + groups - 1) // groups) * xch.bytes_per_epoch()
     x = alloc_resident(E, C, T, dev, reserve_bytes=reserve)
@@ -557,16 +564,18 @@ def run_rank(args):
 
     # non-default variants of the tokenizer tail, same chunk, outside the timed region (reported, never `value`)
     variants = {}
-    if rank == 0 and args.shape == "S" and not args.fold_proj and args.vq == "fp32" and args.conv == "fp32":
+    if run_variants:
         base_ms = sum(v["ms"] for v in stages.values())
-        for name, kw in (("fp32+fold_projection", dict(fold_projection=True)),
+        for name, kw in (("fp32_unfolded_projection", dict(fold_projection=False)),
                          ("vq_bf16x6", dict(vq_method="bf16x6")),
                          ("vq_bf16x6+conv_bf16x6", dict(vq_method="bf16x6", conv_method="bf16x6")),
                          ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True)),
                          ("vq_bf16x6+conv_bf16x6+fold_projection", dict(vq_method="bf16x6", conv_method="bf16x6", fold_projection=True))):
             vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, **kw)
             vp = lbm_amd.EpochPipeline(vcfg, taps, A, b, weights, codebook, device=dev)
-            vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z is unused when folded)
+            vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers
+            if not vcfg.fold_projection and "z" not in vp._buf:  # the unfolded variants write z (6.3 GB per 16384-epoch chunk)
+                vp._buf["z"] = z_var
             vp.run(x[:chunk])
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
