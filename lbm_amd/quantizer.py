@@ -247,6 +247,7 @@ class VectorQuantizerEMA(nn.Module):
         self.register_buffer('ema_w', torch.zeros_like(self.embedding.weight.data))
         self._ee_key = None
         self._ee = None
+        self._cb_epoch = 0          # counts in-place codebook rewrites (EMA steps), which autograd versions do not see
 
     def _e_sqnorm(self) -> torch.Tensor:
         w = self.embedding.weight
@@ -291,6 +292,7 @@ class VectorQuantizerEMA(nn.Module):
                 # the kernel rewrote the codebook through its raw pointer (no autograd version bump): the cached |e|^2
                 # belongs to the old rows (the reference recomputes sum(weight**2) every call, training/model.py:91)
                 self._ee_key = self._ee = None
+                self._cb_epoch += 1
         if self.training or grad_path:
             e_latent_loss = F.mse_loss(quantized.detach(), inputs)
             q_latent_loss = F.mse_loss(quantized, inputs.detach())
@@ -331,24 +333,44 @@ class VQVAE(nn.Module):
         x_recon = self.decoder(quantized.permute(0, 2, 1).contiguous())
         return vq_loss, x_recon, perplexity, indices
 
+    def _folded_codebook(self):
+        """(codebook', e_sqnorm') of ``fold_projection`` for the current weights, recomputed when the codebook or the last encoder
+        layer changes (keyed on storage pointer + autograd version + the quantizer's in-place EMA update counter)."""
+        w, pw, pb = self.vq_layer.embedding.weight, self.encoder[6].weight, self.encoder[6].bias
+        key = (w.data_ptr(), w._version, pw.data_ptr(), pw._version, pb.data_ptr(), pb._version, str(w.device), self.vq_layer._cb_epoch)
+        if getattr(self, "_fold_key", None) != key:
+            self._fold = fold_projection(w.detach(), pw.detach(), pb.detach())
+            self._fold_key = key
+        return self._fold
+
     @torch.no_grad()
-    def encode(self, x, hist=None):
+    def encode(self, x, hist=None, fold_projection: bool = False):
         """Input x[B, C, L] -> code indices int64 [B, L//4] (training/model.py:206-214), all on HIP kernels;
-        the encoder output is consumed channel-major, so the permute(0,2,1).contiguous() copy disappears."""
+        the encoder output is consumed channel-major, so the permute(0,2,1).contiguous() copy disappears.
+        ``fold_projection=True``: the last 1x1 convolution is folded into the codebook (see ``fold_projection``): its GEMM and
+        the z tensor disappear; indices equal the default's except at documented fp32 near-ties."""
+        if fold_projection:
+            h = x
+            for i, (st, pd) in zip((0, 2, 4), ((2, 1), (2, 1), (1, 1))):
+                h = conv1d(h, self.encoder[i].weight, self.encoder[i].bias, st, pd, True, pitched_out=True)
+            cbf, eef = self._folded_codebook()
+            idx = vq_argmin(h, cbf, eef, channel_major=True, no_xnorm=True, hist=hist)
+            return idx.view(x.shape[0], -1)
         z = encoder_forward(x, self.encoder, pitched_out=True)
         idx = self.vq_layer.get_code_indices_channel_major(z, hist=hist)
         return idx.view(x.shape[0], -1)
 
 
-def encode_data_for_transformer(vq_model, dataloader, device):
+def encode_data_for_transformer(vq_model, dataloader, device, fold_projection: bool = False):
     """training/model.py:411-427: returns (np.int64 [E, S] indices, np labels).  Batches are encoded
-    back-to-back on the device; indices come back to the host once, after the loop."""
+    back-to-back on the device; indices come back to the host once, after the loop.  ``fold_projection`` (not a reference
+    argument) is handed to ``VQVAE.encode``."""
     vq_model.eval()
     all_indices, all_labels = [], []
     with torch.no_grad():
         for data, labels in dataloader:
             data = data.to(device, non_blocking=True)
-            all_indices.append(vq_model.encode(data))
+            all_indices.append(vq_model.encode(data, fold_projection=True) if fold_projection else vq_model.encode(data))
             all_labels.append(labels.numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels))
     all_indices = torch.cat(all_indices, dim=0).cpu().numpy()
     all_labels = np.concatenate(all_labels, axis=0)

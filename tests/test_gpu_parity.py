@@ -633,6 +633,38 @@ def test_vq_histogram_up_to_32768_codes():
         lbm_amd.vq_argmin(torch.zeros(4, 8, device=DEV), torch.zeros(K, 8, device=DEV), hist=torch.zeros(K, dtype=torch.int64, device=DEV))
 
 
+def test_vqvae_encode_folded_projection_option(shipped, vq_golden):
+    """VQVAE.encode(x, fold_projection=True) / encode_data_for_transformer(..., fold_projection=True): the reference's own
+    golden tokens except documented near-ties; the folded codebook is cached and follows weight changes."""
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
+    m = m.to(DEV).eval()
+    cb = shipped["vq_layer.embedding.weight"]
+    for name in ("S", "R", "P"):
+        x = torch.from_numpy(vq_golden[f"x_{name}"]).to(DEV)
+        tok = m.encode(x, fold_projection=True).cpu().numpy()
+        ref = vq_golden[f"tokens_{name}"]
+        assert tok.shape == ref.shape and tok.dtype == np.int64
+        zg = np.transpose(vq_golden[f"z_{name}"], (0, 2, 1)).reshape(-1, 256)
+        assert orc.vq_near_tie_ok(zg, cb, tok.reshape(-1), ref.reshape(-1)).all()
+        assert (tok == ref).mean() >= 0.97
+    f1 = m._folded_codebook()
+    assert m._folded_codebook() is f1                       # cached
+    with torch.no_grad():
+        m.encoder[6].bias.add_(0.5)                         # a weight change (version bump) invalidates it
+    f2 = m._folded_codebook()
+    assert f2 is not f1 and not torch.equal(f2[1], f1[1])
+    x = torch.from_numpy(vq_golden["x_P"]).to(DEV)
+    assert torch.equal(m.encode(x, fold_projection=True), m.encode(x)) or \
+        orc.vq_near_tie_ok(lbm_amd.encoder_forward(x, m.encoder).permute(0, 2, 1).reshape(-1, 256).cpu().numpy(), cb,
+                           m.encode(x, fold_projection=True).cpu().numpy().reshape(-1), m.encode(x).cpu().numpy().reshape(-1)).all()
+    data = torch.randn(70, 30, 39, generator=torch.Generator().manual_seed(2))
+    dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, torch.arange(70) % 3), batch_size=32)
+    a, la = lbm_amd.encode_data_for_transformer(m, dl, torch.device(DEV), fold_projection=True)
+    b_, lb = lbm_amd.encode_data_for_transformer(m, dl, torch.device(DEV))
+    assert a.shape == b_.shape == (70, 9) and np.array_equal(la, lb) and (a == b_).mean() >= 0.97
+
+
 def test_vq_ema_training_step_golden(shipped, vq_golden):
     """VectorQuantizerEMA.forward in training mode: EMA buffers and codebook after one step (training/model.py:103-126)."""
     m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
