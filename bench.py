@@ -42,7 +42,7 @@ def _import_product():
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
-KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine_post": "affine_post_kernel<1,6,true>", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_fold_kernel",
+KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine_post": "affine_post_kernel<1,6,true>", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_team_kernel<2,1>",
                    "bandpower": "bandpower_kernel", "conv1": "conv_tile_kernel<4,2,64>", "conv2": "conv_tile_kernel<4,2,128>",
                    "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1,1,256>", "vq": "vq_argmin_dma_kernel"}
 

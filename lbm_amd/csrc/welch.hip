@@ -106,11 +106,18 @@ __global__ __launch_bounds__(kThreads) void welch_tables_kernel(void* tables, in
         double s = 0.0;
         for (int i = 0; i < kThreads; ++i) s += s_part[i];
         *reinterpret_cast<double*>(p) = s;
+        // header int at byte 8: 1 when the per-segment mean cannot reach the requested bins -- the DFT of a full-length periodic
+        // Hann / Hamming window is zero outside bins 0 and +-1 (boxcar: outside bin 0), so sum_n w[n] m e^{-2 pi i k n / N} = 0
+        // exactly for every requested k and the mean removal of scipy's detrend='constant' is a no-op there
+        const bool mean_free = nperseg == nfft && ((window_id == LBM_WIN_BOXCAR && bin_lo >= 1) ||
+                                                   ((window_id == LBM_WIN_HANN || window_id == LBM_WIN_HAMMING) && bin_lo >= 2));
+        reinterpret_cast<int*>(p)[2] = mean_free ? 1 : 0;
     }
 }
 
 // ------------------------------------------------------------------------------------------ fast path
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 constexpr int kLdp = 33;  // row stride of the per-wave power buffer
 
 struct FoldGeom {
@@ -391,6 +398,262 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ team path (round 2)
+// welch_team_kernel<TS, NTILES>: the arithmetic of welch_fold_kernel with the k-steps of a 16-segment tile SPLIT over the TS
+// wavefronts of a workgroup (= one team) that share one staged row group.  The fold kernel is bound by instruction issue and
+// LDS round trips at 1-2 waves per SIMD (phase stamps, round 2: stage 5.0 k / means 3.2 k / fold 10.6 k / average 2.1 k cycles
+// per 3-row group and wave; the fold's 128 MFMAs are 4.1 k of that), and what limits its waves is LDS: 33-66 KB of basis per
+// workgroup plus 18 KB (30 x 1500) to 40 KB (config 5's 10 000-sample rows) of staged rows PER WAVE.  Splitting the transform
+// length over TS waves changes both terms: a wave now needs only 1/TS of the basis -- <= 16 k-steps x float4 = 64 VGPRs, so the
+// basis lives in REGISTERS and leaves LDS (and the fold loses its one ds_read_b128 per step) -- and TS waves share one copy of
+// the rows.  A workgroup is 25 KB (70 KB) of LDS: 6 teams of 2 = 12 waves per CU at 30 x 1500, 2 teams of 4 at config 5 (was 6
+// and 2 waves).  Teams are separate workgroups, so their phases drift apart and one team's transfers overlap another's
+// transforms; the barriers are team-local.  Rows reach LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write): the NEXT group is requested the moment the fold has finished with the row buffer and flies under the exchange /
+// average / store of this one.  The partial transforms (4 accumulators per tile and wave) are summed through LDS by the tile's
+// owner wave, in ascending wave order; the segment average and the store are spread over the team.  Where the per-segment
+// mean cannot reach the requested bins (table header flag: full-length Hann / Hamming and bin_lo >= 2, boxcar and bin_lo >= 1)
+// the means phase is gone: the fold subtracts the segment's FIRST SAMPLE instead (any constant is annihilated exactly there;
+// this one keeps the sums well conditioned for rows with a large offset).
+constexpr int kTeamSteps = 16;  // k-steps per wave held in registers (QS / TS rounded up must not exceed it)
+
+__host__ __device__ inline int team_rows_pad(int rows_floats) { return (rows_floats + 255) & ~255; }   // whole 1 KiB DMA units
+
+template <int TS, int NTILES>
+__global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 2 && NTILES == 1) ? 3 : 2, (TS == 2 && NTILES == 1) ? 3 : 2))) void welch_team_kernel(
+    const float* __restrict__ x, const float* __restrict__ row_scale, float* __restrict__ psd, int64_t rows, int T, double fs, FoldGeom g,
+    const void* __restrict__ tables, int bin_lo, int F, int64_t ngroups) {
+    extern __shared__ __align__(16) float smem[];
+    float* s_rows = smem;                                            // [RW][T], padded to whole DMA units
+    float4* s_part = reinterpret_cast<float4*>(s_rows + team_rows_pad(g.rows_floats));   // [NTILES][TS-1][4][64] float4
+    float* s_P = reinterpret_cast<float*>(s_part + NTILES * (TS - 1) * 4 * 64);          // [NTILES*16][kLdp]
+    float* s_mean = s_P + NTILES * 16 * kLdp;                        // [NTILES*16]
+    float* s_win = s_mean + NTILES * 16;                             // [H+1]
+    const int lane = threadIdx.x & 63, tw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tw in an SGPR: its branches are scalar
+    const int j = lane & 15, kq = lane >> 4;
+
+    // rows of a group -> LDS: unit u = 64 lanes x 16 bytes; the calling wave moves units first, first + stride, ...  Lanes past
+    // the end of the group re-read its last quad into the padding of the row buffer.
+    auto request_rows = [&](int64_t grp, int first, int stride) {
+        const int64_t row0 = grp * g.RW;
+        const int nrows = (int)((rows - row0) < g.RW ? (rows - row0) : g.RW);
+        const int n4 = (nrows * T) >> 2;
+        const float4* src4 = reinterpret_cast<const float4*>(x + row0 * (int64_t)T);
+        const int units = (n4 + 63) >> 6;
+        for (int u = first; u < units; u += stride) {
+            const int idx = u * 64 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src4 + (idx < n4 ? idx : n4 - 1)),
+                                             (__attribute__((address_space(3))) void*)(s_rows + u * 256), 16, 0, 0);
+        }
+    };
+    if ((int64_t)blockIdx.x < ngroups) request_rows(blockIdx.x, tw, TS);
+
+    const TableView tv = view_tables(tables, g.N, g.N);
+    const int mean_free = reinterpret_cast<const int*>(tables)[2];
+    for (int i = threadIdx.x; i <= g.H; i += 64 * TS) s_win[i] = tv.window[i];
+    // this wave's k-steps [t_lo, t_hi) and its slice of the folded basis (bin slot j, sample n = 4 t + kq), in registers
+    const int t_lo = (tw * g.QS) / TS, t_hi = ((tw + 1) * g.QS) / TS;
+    float4 breg[kTeamSteps];
+#pragma unroll
+    for (int st = 0; st < kTeamSteps; ++st) {
+        const int t = t_lo + st < g.QS ? t_lo + st : g.QS - 1;
+        breg[st] = reinterpret_cast<const float4*>(tv.basis)[j * g.KD + 4 * t + kq];
+    }
+
+    // window slices of the fast steps, in registers: {w[n], w[H - n]}; ZERO for the steps of the straight line the wave does
+    // not own (t >= t_hi) and for the two end steps (general form below): those then add exact zeros
+    f32x2 wv[kTeamSteps];
+#pragma unroll
+    for (int st = 0; st < kTeamSteps; ++st) {
+        const int t = t_lo + st, n = 4 * t + kq;
+        const bool own = t < t_hi && t != 0 && 4 * t + 3 < g.Q;
+        const int nc = own ? n : 1;
+        const float w1 = tv.window[nc], w2 = tv.window[g.H - nc];
+        wv[st] = own ? (f32x2){w1, w2} : (f32x2){0.f, 0.f};
+    }
+    const float4 b_last = reinterpret_cast<const float4*>(tv.basis)[j * g.KD + 4 * (g.QS - 1) + kq];
+
+    const double scale = 1.0 / (fs * (*tv.sum_w2));
+    const double scale2 = scale * 2.0;
+    const float inv_n = 1.f / (float)g.N;
+    const float inv_F = 1.f / (float)F;
+    const int ke0 = bin_lo + (bin_lo & 1), ko0 = bin_lo + 1 - (bin_lo & 1);
+
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int64_t row0 = grp * g.RW;
+        const int nrows = (int)((rows - row0) < g.RW ? (rows - row0) : g.RW);
+        const int nsegs = nrows * g.nseg;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // B: this group's rows have landed (first group: the window too)
+        // ---- per-segment means (scipy detrend='constant') -- only where the mean can reach the requested bins
+        if (!mean_free) {   // uniform
+            for (int sg0 = 16 * tw; sg0 < NTILES * 16; sg0 += 16 * TS) {
+                const int sg = sg0 + (lane >> 2), part = lane & 3;
+                const int sgc = sg < nsegs ? sg : nsegs - 1;
+                const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
+                float sum = 0.f;
+                for (int n = part; n < g.N; n += 4) sum += base[n];
+                sum += __shfl_xor(sum, 1, 64);
+                sum += __shfl_xor(sum, 2, 64);
+                if (part == 0 && sg < nsegs) s_mean[sg] = sum * inv_n;
+            }
+            __syncthreads();
+        }
+        // ---- folded pruned DFT: this wave's k-steps of every tile.  Steps with 0 < n < Q on every lane ("fast": all but
+        // t = 0 and t = QS - 1) run as ONE straight line of kTeamSteps steps from immediate LDS offsets -- no branches, no
+        // clamps, window and basis from registers, packed f32 arithmetic: the VALU port, not the MFMA pipe, was what the
+        // fold kernel saturated.  Steps of that line the wave does not own carry zero weights.  The two end steps take the
+        // general form under a uniform branch.
+        f32x4 accs[NTILES][4];   // [tile][re_e, im_e, re_o, im_o]
+#pragma unroll
+        for (int tile = 0; tile < NTILES; ++tile) {
+            const int sg = tile * 16 + j;
+            const int sgc = sg < nsegs ? sg : 0;
+            const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
+            const float m = mean_free ? base[0] : s_mean[sgc];
+            const float m2 = 2.f * m;
+            f32x4 acc[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // opaque copy of the lane's k offset: keeps the operand addresses from being hoisted out of the group loop as
+            // loop invariants (they would occupy registers there for nothing)
+            int kqv = kq;
+            asm volatile("" : "+v"(kqv));
+            auto generic = [&](int t, const float4 bs) {
+                const int n = 4 * t + kqv;
+                const int nc = n < g.Q ? n : g.Q;
+                const float d1 = base[nc] - m, d3 = base[g.H - nc] - m;
+                float d2 = base[g.N - (nc ? nc : 1)] - m;   // d[N - n]; d[N] does not exist
+                float d4 = base[g.H + nc] - m;              // d[H + n]; at n == 0 it is d[H] again
+                if (nc == 0) { d2 = 0.f; d4 = 0.f; }
+                const float w1 = n <= g.Q ? s_win[nc] : 0.f, w2 = n <= g.Q ? s_win[g.H - nc] : 0.f;   // k-slots past the middle term
+                const float a1 = w1 * (d1 + d2), a2 = w2 * (d3 + d4);
+                const float b1 = w1 * (d1 - d2), b2 = w2 * (d3 - d4);
+                const float f = (nc == g.Q) ? 0.5f : 1.f;   // the middle term pairs with itself
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f * (a1 + a2), bs.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1 - b2, bs.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1 - a2, bs.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(f * (b1 + b2), bs.w, acc[3], 0, 0, 0);
+            };
+            const int n0 = 4 * t_lo + kqv;                  // this lane's sample at st = 0
+            const float* p1 = base + n0;                    // d[n]      at p1[4 st]
+            const float* p4 = base + g.H + n0;              // d[H + n]  at p4[4 st]
+            const float* p3 = base + g.H - n0;              // d[H - n]  at p3[-4 st]
+            const float* p2 = base + g.N - n0;              // d[N - n]  at p2[-4 st]
+            struct Ld { f32x2 da, db; };                    // {d1, d3}, {d2, d4}
+            auto load = [&](int st) {
+                Ld o;
+                o.da.x = p1[4 * st]; o.db.y = p4[4 * st]; o.da.y = p3[-4 * st]; o.db.x = p2[-4 * st];
+                return o;
+            };
+            const f32x2 m2v = {m2, m2};
+            auto fast = [&](const Ld& o, const f32x2 w, const float4 bs) {
+                const f32x2 a = w * ((o.da + o.db) - m2v);  // {a1, a2}
+                const f32x2 b = w * (o.da - o.db);          // {b1, b2}
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x + a.y, bs.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x - b.y, bs.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x - a.y, bs.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x + b.y, bs.w, acc[3], 0, 0, 0);
+            };
+            // st = 0: t = 0 on wave 0 (there d[N - n] of lane n = 0 would be another segment's sample: never read it)
+            if (t_lo == 0) generic(0, breg[0]);             // uniform
+            else fast(load(0), wv[0], breg[0]);
+            Ld cur = load(1);
+#pragma unroll
+            for (int st = 1; st < kTeamSteps; ++st) {
+                Ld nxt = cur;
+                if (st + 1 < kTeamSteps) nxt = load(st + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                fast(cur, wv[st], breg[st]);
+                __builtin_amdgcn_sched_barrier(0);
+                cur = nxt;
+            }
+            if (t_hi == g.QS) generic(g.QS - 1, b_last);    // uniform: the last wave owns the middle term
+#pragma unroll
+            for (int a = 0; a < 4; ++a) accs[tile][a] = acc[a];
+        }
+        __syncthreads();   // C: every wave of the team is done reading the rows (and, from the previous group, P)
+        // ---- the NEXT group's rows are requested as soon as the row buffer is free; they land under the rest of this
+        // iteration.  An LDS-DMA piece costs its wave ~200 cycles of issue here (stamps), so the pieces are spread: over both
+        // waves of a team of two; in a team of four over the waves that own no tile, while the owners sum (after barrier D).
+        constexpr bool kSpareWaves = TS > 2 && NTILES < TS;
+        if (!kSpareWaves) {
+            const int64_t nxt = grp + gridDim.x;
+            if (nxt < ngroups) request_rows(nxt, tw, TS);   // uniform
+        }
+        // ---- partial transforms of the non-owner waves -> LDS.  Tile `tile` is owned by wave tile % TS.
+#pragma unroll
+        for (int tile = 0; tile < NTILES; ++tile) {
+            const int owner = tile % TS;
+            if (tw != owner) {   // uniform
+                const int slot = tw < owner ? tw : tw - 1;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    s_part[((tile * (TS - 1) + slot) * 4 + a) * 64 + lane] =
+                        make_float4(accs[tile][a][0], accs[tile][a][1], accs[tile][a][2], accs[tile][a][3]);
+            }
+        }
+        __syncthreads();   // D
+        if (kSpareWaves && tw >= NTILES) {   // uniform
+            const int64_t nxt = grp + gridDim.x;
+            if (nxt < ngroups) request_rows(nxt, tw - NTILES, TS - NTILES);
+        }
+        // ---- the owner sums the partials in ascending wave order, |X|^2 -> P.  Accumulator layout: column = bin slot j
+        // (lane & 15), rows = segments 4 kq + r
+#pragma unroll
+        for (int tile = 0; tile < NTILES; ++tile) {
+            const int owner = tile % TS;
+            if (tw == owner) {   // uniform
+                float4 sum[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) sum[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int w = 0; w < TS; ++w) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        float4 v;
+                        if (w == owner) {
+                            v = make_float4(accs[tile][a][0], accs[tile][a][1], accs[tile][a][2], accs[tile][a][3]);
+                        } else {
+                            v = s_part[((tile * (TS - 1) + (w < owner ? w : w - 1)) * 4 + a) * 64 + lane];
+                        }
+                        sum[a].x += v.x; sum[a].y += v.y; sum[a].z += v.z; sum[a].w += v.w;
+                    }
+                }
+#pragma unroll
+                for (int odd = 0; odd < 2; ++odd) {
+                    const float4 re = sum[2 * odd], im = sum[2 * odd + 1];
+                    const int ib = (odd ? ko0 : ke0) + 2 * j - bin_lo;
+                    if (ib < F) {
+                        float* prow = s_P + (tile * 16 + 4 * kq) * kLdp + ib;
+                        prow[0] = fmaf(re.x, re.x, im.x * im.x);
+                        prow[kLdp] = fmaf(re.y, re.y, im.y * im.y);
+                        prow[2 * kLdp] = fmaf(re.z, re.z, im.z * im.z);
+                        prow[3 * kLdp] = fmaf(re.w, re.w, im.w * im.w);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // E: P complete
+        // ---- segment average (ascending segment order), scaling, store: spread over the team
+        const int nout = nrows * F;
+        for (int o = threadIdx.x; o < nout; o += 64 * TS) {
+            const int r = (int)(((float)o + 0.5f) * inv_F), fb = o - r * F;   // o / F (exact: o < 16 F, F < 2^10)
+            float acc = 0.f;
+            for (int sgi = 0; sgi < g.nseg; ++sgi) acc += s_P[(r * g.nseg + sgi) * kLdp + fb];
+            const int k = bin_lo + fb;
+            double sc = (k == 0 || k == g.H) ? scale : scale2;
+            if (row_scale != nullptr) {
+                const double rs = (double)row_scale[row0 + r];
+                sc *= rs * rs;
+            }
+            psd[row0 * F + o] = (float)((double)(acc / (float)g.nseg) * sc);
+        }
+        // the next group writes the partials after its barrier C and P after its barrier D: every wave has left this average
+        // by then
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void welch_kernel(const float* __restrict__ x, const float* __restrict__ row_scale,
                                                          float* __restrict__ psd,
                                                          float* __restrict__ seg_out, int T, double fs, int nfft,
@@ -545,6 +808,30 @@ int welch_impl(const float* x, const float* row_scale, float* psd, float* seg_or
         n_odd <= 16 && nseg >= 1) {
         const FoldGeom g = fold_geom(nfft, T, hop, nseg);
         const size_t shared_floats = (size_t)16 * g.LDB + ((g.H + 1 + 3) & ~3);
+        // team path: 16-byte rows; teams (= workgroups) of 2 waves, of 4 for long rows
+        if (((T & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && g.TILES <= 2) {
+            const int ts = g.rows_floats <= 6000 ? 2 : 4;
+            const size_t lds_t = ((size_t)team_rows_pad(g.rows_floats) + (size_t)g.TILES * (ts - 1) * 1024 +
+                                  (size_t)g.TILES * 16 * (kLdp + 1) + ((g.H + 1 + 3) & ~3)) * sizeof(float);
+            // every step of a wave's straight line must stay inside its segment: n <= H for the last wave's last step
+            const bool in_seg = 4 * (((ts - 1) * g.QS) / ts + kTeamSteps - 1) + 3 <= g.H;
+            if ((g.QS + ts - 1) / ts <= kTeamSteps && g.QS >= 2 * ts && in_seg && lds_t <= 80 * 1024) {
+                const int64_t ngroups = (rows + g.RW - 1) / g.RW;
+                int per_cu = (int)((160 * 1024) / lds_t);
+                const int cap = (ts == 2 && g.TILES == 1) ? 6 : 8 / ts;   // the kernels' register budgets: 3 (2) waves per SIMD
+                if (per_cu > cap) per_cu = cap;
+                int64_t blocks = 256LL * per_cu;
+                if (blocks > ngroups) blocks = ngroups;
+                auto k = ts == 2 ? (g.TILES == 1 ? welch_team_kernel<2, 1> : welch_team_kernel<2, 2>)
+                                 : (g.TILES == 1 ? welch_team_kernel<4, 1> : welch_team_kernel<4, 2>);
+                if (lds_t > 48 * 1024 &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t) != hipSuccess)
+                    return lbm::fail(LBM_ELAUNCH, "lbm_welch_f32(team): cannot reserve %zu bytes of LDS", lds_t);
+                hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * ts), lds_t, lbm::as_stream(stream), x, row_scale, psd, rows, T,
+                                   (double)fs, g, tables, bin_lo, F, ngroups);
+                return lbm::check_launch("lbm_welch_f32(team)");
+            }
+        }
         int waves = 6;   // 2 + 2 + 1 + 1 per SIMD: the phases of a group are chains of LDS round trips, other waves fill them
         while (waves > 1 && (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float) > 160 * 1024) --waves;
         const size_t lds_f = (shared_floats + (size_t)waves * g.wave_floats) * sizeof(float);

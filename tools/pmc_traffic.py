@@ -10,7 +10,7 @@ import sys
 root = sys.argv[1]
 E, C, T, S = 16384, 30, 1500, 375
 KERNEL = {"vq": "vq_argmin_dma_kernel", "vqb": "vq_bf16x6_kernel", "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1, 1, 256",
-          "fir": "fir_fft_kernel", "welch_scaled": "welch_fold_kernel", "affine_post": "affine_post_kernel"}
+          "fir": "fir_fft_kernel", "welch_scaled": "welch_team_kernel", "affine_post": "affine_post_kernel"}
 ALGO = {"vq": (256 * S * 4 + S * 8) * E, "vqb": (256 * S * 4 + S * 8) * E, "conv3": (128 * S * 4 + 256 * S * 4) * E,
         "conv4": (256 * S * 4 + 256 * S * 4) * E, "fir": 2 * C * T * 4 * E, "welch_scaled": (C * T * 4 + C * 27 * 4 + C * 4) * E,
         "affine_post": (2 * C * T * 4 + C * 4 + 1) * E}
