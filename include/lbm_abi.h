@@ -274,13 +274,28 @@ int lbm_vq_argmin_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, co
  * the fp32 fmaf chain above (tools/probe/bf16x_probe.hip) at 16/6 of the fp32 matrix rate.  Indices equal those of
  * lbm_vq_argmin_f32 except at fp32 near-ties (SURVEY.md 8(a) rule).  The codebook is passed pre-split:
  * lbm_vq_split_tables_bytes(K, D) sizes a caller-owned, 16-byte aligned device table that
- * lbm_vq_split_tables_init fills from the fp32 codebook [K, D] (0 bytes = unsupported shape).  1 <= D <= 256, any K >= 1.
+ * lbm_vq_split_tables_init fills from the fp32 codebook [K, D] (0 bytes = unsupported shape; the table ends with an upper
+ * bound of every code's norm, which only the screened search below reads).  1 <= D <= 256, any K >= 1.
  * e_sqnorm as above (lbm_rownorm2_f32 of the fp32 codebook, or the folded constants with LBM_VQ_NO_XNORM). */
 size_t lbm_vq_split_tables_bytes(int32_t K, int32_t D);
 int lbm_vq_split_tables_init(void* tables, const float* codebook, int32_t K, int32_t D, lbm_stream_t stream);
 int lbm_vq_argmin_bf16x6_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const void* tables,
                              const float* e_sqnorm, int64_t* idx_out, float* mind_or_null,
                              unsigned long long* hist_or_null, int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
+
+/* lbm_vq_argmin_f32's result -- the SAME indices, bit for bit, ties and near-ties included -- at a fraction of its matrix
+ * time (VectorQuantizerEMA.get_code_indices, training/model.py:152-158).  Pass 1 screens every (row, code) score with three
+ * bf16 piece products on the bf16 matrix cores and a rigorous per-pair bound of its distance from the fp32 fmaf chain's score
+ * (csrc/vq_screen.hip derives it); a row whose best code's upper bound lies below every other code's lower bound is settled.
+ * Pass 2 re-searches the remaining rows (1-2 % on the shipped codebooks; exact duplicates of a code row always) with
+ * lbm_vq_argmin_f32's own kernel code.  tables: lbm_vq_split_tables_init(codebook) (above); codebook / e_sqnorm / layout /
+ * hist_or_null as for lbm_vq_argmin_f32 (no minimum-distance output).  workspace: lbm_vq_screen_workspace_bytes(N) bytes of
+ * caller-owned, 8-byte aligned device memory; after the call its first int32 holds the number of rows pass 2 searched.
+ * D a multiple of 8 and <= 256, N < 2^31. */
+size_t lbm_vq_screen_workspace_bytes(int64_t N);
+int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const float* codebook, const void* tables,
+                               const float* e_sqnorm, int64_t* idx_out, unsigned long long* hist_or_null, void* workspace,
+                               int64_t N, int32_t D, int32_t K, lbm_stream_t stream);
 
 /* VectorQuantizerEMA.forward tail, training/model.py:100,130-139: quantized = E[idx] (returned with the
  * straight-through arithmetic x + (E[idx] - x)), sq_err_sum[0] += sum((E[idx] - x)^2) in float64

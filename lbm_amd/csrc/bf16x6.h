@@ -32,4 +32,19 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p1, bf16x8& p2, b
     }
 }
 
+// Pre-split codebook table of the quantizer kernels: [nst][3][Kp][16] bf16 pieces, then float en[Kp] = an upper bound of |e_k|
+// (the screening kernel's error bound; the six-product kernel does not read it).
+struct VqTabPlan {
+    int Kp, nst;
+    size_t piece_bytes, bytes;
+};
+inline VqTabPlan vq_tab_plan(int K, int D) {
+    VqTabPlan p;
+    p.Kp = (K + kSup - 1) / kSup * kSup;
+    p.nst = (D + kKC - 1) / kKC;
+    p.piece_bytes = (size_t)p.nst * 3 * p.Kp * 32;
+    p.bytes = p.piece_bytes + (size_t)p.Kp * sizeof(float);
+    return p;
+}
+
 }  // namespace

@@ -23,12 +23,17 @@ constexpr int kThreads = 256;
 constexpr int kTileCodes = 64;
 constexpr int kRowsPerBlock = 128;
 
-template <int DP, int LAYOUT>
+// LIST = true is the refinement pass of lbm_vq_argmin_screened_f32: the rows to search are row_list[0 .. *row_count) (any order),
+// walked by a fixed grid; everything else -- fragments, fmaf chains, argmin rule -- is the same code, so a refined row gets
+// exactly the token the full fp32 search gives it.
+template <int DP, int LAYOUT, bool LIST = false>
 __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __restrict__ x, int64_t ldx,
                                                                 const float* __restrict__ codebook,
                                                                 const float* __restrict__ e_sqnorm,
                                                                 int64_t* __restrict__ idx_out, float* __restrict__ mind,
-                                                                int64_t N, int D, int K, int vec_ok, int64_t S, int no_xnorm) {
+                                                                int64_t N, int D, int K, int vec_ok, int64_t S, int no_xnorm,
+                                                                const int64_t* __restrict__ row_list = nullptr,
+                                                                const int* __restrict__ row_count = nullptr) {
     constexpr int HALF = DP / 2;
     constexpr int LDE = DP + 4;
     extern __shared__ __align__(16) float smem[];
@@ -37,8 +42,19 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave * 32 + j;
-    const int64_t row_c = row < N ? row : N - 1;
+    int64_t total = N;
+    if constexpr (LIST) {
+        const int64_t c = *row_count;
+        total = c < N ? c : N;
+    }
+  for (int64_t vb = blockIdx.x; vb * kRowsPerBlock < total; vb += gridDim.x) {
+    const int64_t slot = vb * kRowsPerBlock + wave * 32 + j;
+    int64_t row = slot, row_c = slot < total ? slot : total - 1;
+    if constexpr (LIST) {
+        row_c = row_list[row_c];
+        row_c = row_c < 0 ? 0 : (row_c < N ? row_c : N - 1);
+        row = slot < total ? row_c : N;
+    }
 
     // ---- B fragments: this lane's half of its input row, zero padded to DP
     float bx[HALF];
@@ -165,6 +181,8 @@ __global__ __launch_bounds__(kThreads, 2) void vq_argmin_kernel(const float* __r
         idx_out[row] = (int64_t)bidx;
         if (mind != nullptr) mind[row] = best;
     }
+    if constexpr (!LIST) break;   // one block of rows per workgroup
+  }
 }
 
 // D = 256, K a multiple of 64, 16-byte aligned codebook: the same arithmetic (same ascending fmaf chains, same argmin
@@ -391,12 +409,14 @@ int launch_vq(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, 
         auto k = vq_argmin_kernel<DP, LBM_VQ_ROWS>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S, no_xnorm);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S, no_xnorm,
+                           (const int64_t*)nullptr, (const int*)nullptr);
     } else {
         auto k = vq_argmin_kernel<DP, LBM_VQ_CHANNEL_MAJOR>;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S, no_xnorm);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, mind, N, D, K, vec_ok, S, no_xnorm,
+                           (const int64_t*)nullptr, (const int*)nullptr);
     }
     return lbm::check_launch("lbm_vq_argmin_f32");
 }
@@ -416,6 +436,32 @@ int launch_vq_dma(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t
 }
 
 }  // namespace
+
+namespace {
+template <int DP>
+int launch_refine(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, const float* codebook, const float* e_sqnorm,
+                  int64_t* idx_out, const int64_t* row_list, const int* row_count, int64_t N, int D, int K, hipStream_t st) {
+    const size_t lds = ((size_t)kTileCodes * (DP + 4) + kTileCodes) * sizeof(float);
+    int64_t blocks = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (blocks > 1024) blocks = 1024;
+    const int vec_ok = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
+    auto k = layout == LBM_VQ_ROWS ? vq_argmin_kernel<DP, LBM_VQ_ROWS, true> : vq_argmin_kernel<DP, LBM_VQ_CHANNEL_MAJOR, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_screened_f32(refine): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, (float*)nullptr, N, D, K, vec_ok,
+                       S, no_xnorm, row_list, row_count);
+    return lbm::check_launch("lbm_vq_argmin_screened_f32(refine)");
+}
+}  // namespace
+
+// shared with vq_screen.hip: full fp32 search of the listed rows (list and count live in device memory), with the fragment
+// width lbm_vq_argmin_f32 picks for this D -- the width fixes the order of the fmaf chain, and the point is the same bits
+int lbm_vq_refine_launch(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, const float* codebook, const float* e_sqnorm,
+                         int64_t* idx_out, const int64_t* row_list, const int* row_count, int64_t N, int D, int K, hipStream_t st) {
+    if (D <= 64) return launch_refine<64>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, row_list, row_count, N, D, K, st);
+    if (D <= 128) return launch_refine<128>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, row_list, row_count, N, D, K, st);
+    return launch_refine<256>(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, row_list, row_count, N, D, K, st);
+}
 
 // shared with vq_bf16.hip
 int lbm_vq_hist_launch(const int64_t* idx, unsigned long long* hist, int64_t N, int K, hipStream_t st) {

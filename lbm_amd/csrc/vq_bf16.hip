@@ -276,33 +276,36 @@ __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __r
     }
 }
 
-struct TabPlan {
-    int Kp, nst;
-    size_t bytes;
-};
-TabPlan tab_plan(int K, int D) {
-    TabPlan p;
-    p.Kp = (K + kSup - 1) / kSup * kSup;
-    p.nst = (D + kKC - 1) / kKC;
-    p.bytes = (size_t)p.nst * 3 * p.Kp * 32;
-    return p;
+// en[k] >= |e_k|: fp32 sum of squares (relative error <= D 2^-24), square root, 1e-5 of slack; 0 beyond K
+__global__ __launch_bounds__(256) void vq_code_norms_kernel(const float* __restrict__ codebook, float* __restrict__ en, int K, int Kp, int D) {
+    const int code = blockIdx.x * 256 + threadIdx.x;
+    if (code >= Kp) return;
+    float s = 0.f;
+    if (code < K)
+        for (int d = 0; d < D; ++d) {
+            const float v = codebook[(int64_t)code * D + d];
+            s = fmaf(v, v, s);
+        }
+    en[code] = sqrtf(s) * 1.00001f;
 }
 
 }  // namespace
 
 extern "C" size_t lbm_vq_split_tables_bytes(int32_t K, int32_t D) {
     if (K < 1 || D < 1 || D > 256) return 0;
-    return tab_plan(K, D).bytes;
+    return vq_tab_plan(K, D).bytes;
 }
 
 extern "C" int lbm_vq_split_tables_init(void* tables, const float* codebook, int32_t K, int32_t D, lbm_stream_t stream) {
     LBM_REQUIRE(tables && codebook, LBM_EINVAL, "lbm_vq_split_tables_init: NULL pointer");
     LBM_REQUIRE(K >= 1 && D >= 1 && D <= 256, LBM_EUNSUPPORTED, "lbm_vq_split_tables_init: K=%d, D=%d (1 <= D <= 256)", K, D);
     LBM_REQUIRE(((uintptr_t)tables & 15) == 0, LBM_EINVAL, "lbm_vq_split_tables_init: tables must be 16-byte aligned");
-    const TabPlan p = tab_plan(K, D);
+    const VqTabPlan p = vq_tab_plan(K, D);
     const int64_t items = (int64_t)p.nst * p.Kp * 2;
     hipLaunchKernelGGL(vq_split_tables_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, lbm::as_stream(stream), codebook,
                        static_cast<bf16x8*>(tables), K, p.Kp, D, p.nst);
+    hipLaunchKernelGGL(vq_code_norms_kernel, dim3((unsigned)((p.Kp + 255) / 256)), dim3(256), 0, lbm::as_stream(stream), codebook,
+                       reinterpret_cast<float*>(static_cast<unsigned char*>(tables) + p.piece_bytes), K, p.Kp, D);
     return lbm::check_launch("lbm_vq_split_tables_init");
 }
 
@@ -330,8 +333,8 @@ extern "C" int lbm_vq_argmin_bf16x6_f32(const float* x, int64_t ldx, int32_t lay
                     (long long)N, (long long)S, (long long)ldx);
     LBM_REQUIRE(layout == LBM_VQ_ROWS || (int64_t)D * ldx < 0x7fffffffLL, LBM_EUNSUPPORTED,
                 "lbm_vq_argmin_bf16x6_f32: D * ldx must be below 2^31");
-    const TabPlan p = tab_plan(K, D);
-    LBM_REQUIRE(p.bytes / 16 < 0x7fffffffULL, LBM_EUNSUPPORTED, "lbm_vq_argmin_bf16x6_f32: table too large");
+    const VqTabPlan p = vq_tab_plan(K, D);
+    LBM_REQUIRE(p.piece_bytes / 16 < 0x7fffffffULL, LBM_EUNSUPPORTED, "lbm_vq_argmin_bf16x6_f32: table too large");
     const int64_t blocks = (N + kRows - 1) / kRows;
     LBM_REQUIRE(blocks <= 0x7fffffffLL, LBM_EUNSUPPORTED, "lbm_vq_argmin_bf16x6_f32: grid too large");
     hipStream_t st = lbm::as_stream(stream);

@@ -40,8 +40,10 @@ class PipelineConfig:
                                        # on the baseline offset: Welch removes each segment's mean, peak-to-peak and the
                                        # z-score are offset-invariant -- so False saves one 180 000 B/epoch write
                                        # (the 186 264 B/epoch compulsory figure excludes cleaned epochs)
-    vq_method: str = "fp32"            # 'fp32': exact fmaf chain on the fp32 MFMA; 'bf16x6': fp32 products rebuilt from three
-                                       # bf16 pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
+    vq_method: str = "fp32"            # 'fp32': exact fmaf chain on the fp32 MFMA; 'screen': the SAME tokens, bit for bit, from a
+                                       # bf16 screening pass with a rigorous error bound + the fp32 kernel on the rows it cannot
+                                       # settle (lbm_vq_argmin_screened_f32); 'bf16x6': fp32 products rebuilt from three bf16
+                                       # pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
     conv_method: str = "fp32"          # 'bf16x6': the encoder's 256-channel layers (3rd conv, 1x1 projection) on the bf16 MFMA
                                        # with three-piece operands (conv_bf16.hip; same accuracy vs float64 as the fp32 chain)
     fuse_post: bool = True             # ICA affine + baseline / reject / z-score in one kernel (lbm_affine_post_f32) and Welch on the
@@ -90,10 +92,10 @@ class EpochPipeline:
             if cfg.fold_projection:
                 from .quantizer import fold_projection
                 self.cb_fold, self.ee_fold = fold_projection(self.codebook, self.enc["encoder.6.weight"], self.enc["encoder.6.bias"])
-            if cfg.vq_method not in ("fp32", "bf16x6"):
+            if cfg.vq_method not in ("fp32", "bf16x6", "screen"):
                 raise ValueError(f"vq_method {cfg.vq_method!r}")
             self.vq_tab = None
-            if cfg.vq_method == "bf16x6":
+            if cfg.vq_method in ("bf16x6", "screen"):
                 from .quantizer import vq_split_tables
                 self.vq_tab = vq_split_tables(self.cb_fold if cfg.fold_projection else self.codebook)
             if cfg.conv_method not in ("fp32", "bf16x6"):
@@ -136,6 +138,8 @@ class EpochPipeline:
                      tokens=mk(E, self.S, dt=torch.int64), hist=torch.zeros((self.K,), dtype=torch.int64, device=d))
             if not c.fold_projection:
                 B.update(z=mk(E, self.D, self.P2))
+            if c.vq_method == "screen":
+                B.update(vq_ws=mk(int(self.lib.lbm_vq_screen_workspace_bytes(E * self.S)), dt=torch.uint8))
         self._buf, self._cap = B, E
 
     def reset_hist(self):
@@ -170,7 +174,7 @@ class EpochPipeline:
         if (C, T) != (c.n_channels, c.n_times):
             raise ValueError(f"expected [E, {c.n_channels}, {c.n_times}], got {tuple(x.shape)}")
         self._reserve(E)
-        B = {k: (v[:E] if k != "hist" else v) for k, v in self._buf.items()}
+        B = {k: (v[:E] if k not in ("hist", "vq_ws") else v) for k, v in self._buf.items()}
         cur = x
         t0 = mark("", None)
         if c.do_filter:
@@ -233,6 +237,11 @@ class EpochPipeline:
             conv(B["h2"], self.P2, B["h3"], self.P2, 4, 128, self.L2, 256, 3, 1, 1, 1)
             t0 = mark("conv3", t0)
             vq = lib.lbm_vq_argmin_f32 if self.vq_tab is None else lib.lbm_vq_argmin_bf16x6_f32
+            if c.vq_method == "screen":
+                def vq(x_, ldx_, layout_, S_, cb_or_tab, ee_, tok_, _mind, hist_, N_, D_, K_, st_, cb=None):
+                    cb = self.cb_fold if c.fold_projection else self.codebook
+                    return lib.lbm_vq_argmin_screened_f32(x_, ldx_, layout_, S_, p(cb), p(self.vq_tab), ee_, tok_, hist_, p(B["vq_ws"]),
+                                                          N_, D_, K_, st_)
             if c.fold_projection:
                 _lib.check(vq(p(B["h3"]), self.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, self.S,
                               p(self.cb_fold if self.vq_tab is None else self.vq_tab), p(self.ee_fold), p(B["tokens"]), None,

@@ -60,11 +60,14 @@ def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
 
 
 def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = None, *, channel_major: bool = False,
-              return_min: bool = False, hist: torch.Tensor = None, no_xnorm: bool = False, split_tables: torch.Tensor = None):
+              return_min: bool = False, hist: torch.Tensor = None, no_xnorm: bool = False, split_tables: torch.Tensor = None,
+              screened: bool = False, return_refined: bool = False):
     """Nearest-code indices (int64).
 
     ``split_tables`` (from ``vq_split_tables(codebook)``) selects the bf16-piece kernel (fp32-grade products on the
-    bf16 matrix cores); without it the fp32-MFMA kernel runs.
+    bf16 matrix cores); without it the fp32-MFMA kernel runs.  ``screened=True`` (needs ``split_tables``, no
+    ``return_min``) returns the fp32-MFMA kernel's indices exactly, from a bf16 screening pass plus an fp32 search of
+    the rows the screen cannot settle (``lbm_vq_argmin_screened_f32``); ``return_refined`` adds that row count.
 
     x: [N, D] rows (any row stride that is a multiple of 1 float), or with ``channel_major`` the encoder
     output z[B, D, S] (N = B*S rows, no permute/contiguous copy).  ``hist`` ([K] int64/uint64 counts) is
@@ -96,6 +99,15 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
         raise ValueError("hist must be a contiguous int64 tensor of K entries")
     if no_xnorm:
         layout |= _lib.VQ_NO_XNORM
+    if screened:
+        if split_tables is None or return_min:
+            raise ValueError("screened=True needs split_tables and has no minimum-distance output")
+        lib = _lib.load()
+        ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(N), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.lbm_vq_argmin_screened_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(cb), _lib.ptr(split_tables), _lib.ptr(e_sqnorm),
+                                                  _lib.ptr(idx), _lib.ptr(hist), _lib.ptr(ws), N, D, K, _lib.stream_ptr()),
+                   "lbm_vq_argmin_screened_f32")
+        return (idx, int(ws[:4].view(torch.int32).item())) if return_refined else idx
     if split_tables is not None:
         _lib.check(_lib.load().lbm_vq_argmin_bf16x6_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(split_tables), _lib.ptr(e_sqnorm),
                                                         _lib.ptr(idx), _lib.ptr(mind), _lib.ptr(hist), N, D, K, _lib.stream_ptr()),

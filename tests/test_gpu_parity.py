@@ -522,6 +522,98 @@ def test_vq_bf16x6_golden_and_duplicates(shipped, vq_golden):
     assert got.tolist() == [17, 17, 17, 5]
 
 
+@pytest.mark.parametrize("N,D,K", [(1000, 256, 512), (129, 256, 8192), (77, 64, 100), (300, 128, 65), (5, 72, 7), (128, 256, 1),
+                                   (4000, 248, 300), (20000, 256, 512)])
+def test_vq_screened_is_the_fp32_kernel_bit_for_bit(N, D, K):
+    """lbm_vq_argmin_screened_f32 (bf16 screening pass with a rigorous bound + fp32 search of the unsettled rows): EXACTLY the
+    indices of lbm_vq_argmin_f32, on spread-out rows, rows at and next to midpoints between codes, copies of codes, tiny and huge
+    rows -- in both layouts, with and without the row constant, histogram included."""
+    rs = np.random.RandomState(N + K)
+    scale = rs.choice([0.3, 1.0, 30.0], size=(K, 1))
+    cb = (rs.randn(K, D) * scale).astype(np.float32)                                          # norms over two decades
+    x = (cb[rs.randint(0, K, N)] + 0.7 * rs.randn(N, D)).astype(np.float32)
+    q = N // 5
+    small = np.flatnonzero(scale[:, 0] == 0.3)                 # midpoints of two short codes: those two are the nearest, and tie
+    small = small if small.size >= 2 else np.arange(K)
+    i0, i1 = small[rs.randint(0, small.size, q)], small[rs.randint(0, small.size, q)]
+    x[:q] = 0.5 * (cb[i0] + cb[i1])                                                            # exact midpoints
+    x[q:2 * q] = x[:q] * (1 + 1e-7) + 1e-6 * rs.randn(q, D)                                    # next to them
+    x[2 * q:2 * q + min(q, K)] = cb[:min(q, K)]                                                # the codes themselves
+    if N > 10:
+        x[-3] *= 1e4; x[-2] *= 1e-5; x[-1] = 0.0
+    xd, cbd = torch.from_numpy(x).to(DEV), torch.from_numpy(cb).to(DEV)
+    tab = lbm_amd.vq_split_tables(cbd)
+    for no_xnorm in (False, True):
+        ee = torch.from_numpy((cb.astype(np.float64) ** 2).sum(1) - (3.0 * cb[:, 0] if no_xnorm else 0.0)).to(DEV, torch.float32)
+        hist0 = torch.zeros(K, dtype=torch.int64, device=DEV)
+        hist1 = torch.zeros(K, dtype=torch.int64, device=DEV)
+        ref = lbm_amd.vq_argmin(xd, cbd, ee, no_xnorm=no_xnorm, hist=hist0)
+        got, nref = lbm_amd.vq_argmin(xd, cbd, ee, no_xnorm=no_xnorm, hist=hist1, split_tables=tab, screened=True, return_refined=True)
+        assert torch.equal(got, ref)
+        assert torch.equal(hist0, hist1)
+        assert 0 <= nref <= N
+        if K > 1 and N >= 1000 and not no_xnorm:   # (with the shifted constants the midpoints are no ties)
+            assert nref >= q // 2            # the midpoints cannot be settled by the screen
+            assert nref <= N - N // 4        # and the spread-out rows are
+        wide = torch.full((N, D + 8), float("nan"), device=DEV); wide[:, :D] = xd
+        assert torch.equal(lbm_amd.vq_argmin(wide[:, :D], cbd, ee, no_xnorm=no_xnorm, split_tables=tab, screened=True), ref)
+        if N % 5 == 0:
+            S = N // 5
+            zp = torch.full((5, D, S + 3), float("nan"), device=DEV)                           # pitched channel-major rows
+            zp[:, :, :S] = xd.view(5, S, D).permute(0, 2, 1)
+            assert torch.equal(lbm_amd.vq_argmin(zp[:, :, :S], cbd, ee, channel_major=True, no_xnorm=no_xnorm, split_tables=tab,
+                                                 screened=True), ref)
+
+
+def test_vq_screened_golden_duplicates_and_nan(shipped, vq_golden):
+    cb = shipped["vq_layer.embedding.weight"]
+    cbd = torch.from_numpy(cb).to(DEV)
+    tab = lbm_amd.vq_split_tables(cbd)
+    gx = torch.from_numpy(vq_golden["gci_in"]).to(DEV)
+    assert torch.equal(lbm_amd.vq_argmin(gx, cbd, split_tables=tab, screened=True), lbm_amd.vq_argmin(gx, cbd))
+    for name in ("S", "R", "P"):
+        zg = torch.from_numpy(vq_golden[f"z_{name}"]).to(DEV)
+        tk = lbm_amd.vq_argmin(zg, cbd, channel_major=True, split_tables=tab, screened=True)
+        assert torch.equal(tk, lbm_amd.vq_argmin(zg, cbd, channel_major=True))
+        zr = np.transpose(vq_golden[f"z_{name}"], (0, 2, 1)).reshape(-1, 256)
+        assert orc.vq_near_tie_ok(zr, cb, tk.cpu().numpy(), vq_golden[f"tokens_{name}"].reshape(-1)).all()
+    # exact duplicate codes: the lowest index wins, as in the fp32 kernel (such rows always go through the fp32 pass)
+    rs = np.random.RandomState(2)
+    c2 = rs.randn(300, 256).astype(np.float32)
+    c2[299] = c2[17]; c2[150] = c2[17]
+    x = (c2[[17, 150, 299, 5]] + 1e-3 * rs.randn(4, 256)).astype(np.float32)
+    x = np.concatenate([x, np.full((1, 256), np.nan, np.float32), x[:1] * np.float32(np.inf)])
+    c2d, xd = torch.from_numpy(c2).to(DEV), torch.from_numpy(x).to(DEV)
+    got, nref = lbm_amd.vq_argmin(xd, c2d, split_tables=lbm_amd.vq_split_tables(c2d), screened=True, return_refined=True)
+    assert got.tolist()[:4] == [17, 17, 17, 5]
+    assert torch.equal(got, lbm_amd.vq_argmin(xd, c2d))          # NaN / inf rows: whatever the fp32 kernel says
+    assert nref >= 5
+    with pytest.raises(ValueError):
+        lbm_amd.vq_argmin(xd, c2d, screened=True)
+    with pytest.raises(ValueError):
+        lbm_amd.vq_argmin(xd, c2d, split_tables=lbm_amd.vq_split_tables(c2d), screened=True, return_min=True)
+
+
+@pytest.mark.parametrize("fold", [False, True])
+def test_pipeline_screened_quantizer_is_bit_identical(shipped, fold):
+    """vq_method='screen': every output of the pipeline equals the fp32 quantizer's, tokens and histogram bit for bit."""
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    cb = shipped["vq_layer.embedding.weight"]
+    mk = lambda m: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=fold, vq_method=m, emit_cleaned=False),  # noqa: E731
+                                         taps, A, b, shipped, cb)
+    x = (synth_epochs(200, 30, 1500, seed=41) * 2.0).to(DEV)
+    ref = {k: v.clone() for k, v in mk("fp32").run(x).items()}
+    pipe = mk("screen")
+    for _ in range(2):          # twice: the workspace and its row counter are reused
+        out = pipe.run(x)
+        assert torch.equal(out["tokens"], ref["tokens"])
+        assert torch.equal(out["psd"], ref["psd"]) and torch.equal(out["keep"], ref["keep"])
+    n_ref = int(pipe._buf["vq_ws"][:4].view(torch.int32).item())
+    assert 0 < n_ref < 0.1 * ref["tokens"].numel()
+    assert torch.equal(out["hist"], 2 * ref["hist"])
+
+
 def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
     m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)

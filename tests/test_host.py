@@ -113,7 +113,7 @@ def test_argument_validation_without_launch():
     assert b"larger than the number of samples" in lib.lbm_last_error()
     assert lib.lbm_welch_tables_bytes(500, 500, 4, 30) >= 64 + 4 * 1500
     # the bf16-piece entry points and the resampler
-    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 and lib.lbm_vq_split_tables_bytes(512, 300) == 0
+    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 + 512 * 4 and lib.lbm_vq_split_tables_bytes(512, 300) == 0
     assert lib.lbm_conv1d_split_tables_bytes(128, 256, 3) == 24 * 3 * 256 * 32
     assert lib.lbm_conv1d_split_tables_bytes(30, 64, 4) == 8 * 3 * 256 * 32            # Cin -> 32, Cout -> 256
     assert lib.lbm_conv1d_split_tables_bytes(5000, 64, 4) == 0
@@ -125,3 +125,35 @@ def test_argument_validation_without_launch():
     assert lib.lbm_resample_length(1800000, 250, 500) == 900000 and lib.lbm_resample_length(1000, 3, 7) == 429   # any ratio
     assert lib.lbm_resample_length(3, 1, 2) == 0 and lib.lbm_resample_workspace_bytes(2, 1000, 3, 7) > 2 * 2 * 2048 * 8
     assert lib.lbm_resample_fft_f32(None, 1000, None, 500, 2, 1000, 3, 7, None, None) < 0
+
+
+def test_lds_dma_kernels_do_not_spill():
+    """lbm_amd/build.py records every kernel's register use; the kernels that move data with LDS-DMA must be spill-free (a
+    spilling build of the screening kernel returned wrong tokens: build.py NO_SPILL_KERNELS)."""
+    import json
+    from lbm_amd import build as b
+    path = os.path.join(os.path.dirname(b.__file__), "csrc", "_obj", "resources.json")
+    if not os.path.exists(path):
+        pytest.skip("library was not built by lbm_amd.build in this tree")
+    with open(path) as f:
+        rep = json.load(f)
+    seen = 0
+    for fname, kernels in rep.items():
+        for k, v in kernels.items():
+            if any(n in k for n in b.NO_SPILL_KERNELS):
+                seen += 1
+                assert v.get("VGPRs Spill", 0) == 0 and v.get("ScratchSize", 0) == 0, (fname, k, v)
+    assert seen >= 8
+
+
+def test_vq_screen_workspace_and_arguments():
+    lib = _lib.load()
+    assert lib.lbm_vq_screen_workspace_bytes(0) == 256
+    assert lib.lbm_vq_screen_workspace_bytes(1000) == 256 + 8000
+    assert lib.lbm_vq_screen_workspace_bytes(-1) == 0
+    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 + 512 * 4      # pieces + the code-norm tail
+    # argument validation happens before any launch
+    assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 0, 256, 512, None) == 0   # N == 0
+    assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
+    assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 250, 512, None) == -2
+    assert lib.lbm_vq_argmin_screened_f32(None, 256, 7, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
