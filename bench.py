@@ -41,14 +41,18 @@ def _import_product():
     lbm_amd, synth_codebook, synth_epochs, synth_ica = _pkg, _cb, _ep, _ica
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine_post": "affine_post_kernel<1,6,true>", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_team_kernel<2,1>",
                    "bandpower": "bandpower_kernel", "conv1": "conv_tile_kernel<4,2,64>", "conv2": "conv_tile_kernel<4,2,128>",
                    "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1,1,256>", "vq": "vq_argmin_dma_kernel"}
+KERNEL_OF_VQ = {"fp32": "vq_argmin_dma_kernel", "bf16x6": "vq_bf16x6_kernel", "screen": "vq_screen_kernel<1> (+ vq_argmin_kernel<256,1,true> on the unsettled rows)"}
 
 
-def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False):
-    """Algorithmic flops / compulsory HBM bytes per launch of each stage over E epochs (SURVEY.md 8d figures)."""
+def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, vq_method="fp32"):
+    """Algorithmic flops / compulsory HBM bytes per launch of each stage over E epochs (SURVEY.md 8d figures).  `flops` is the
+    reference's arithmetic; where a kernel executes something else (Winograd: 2/3 of the products; the screened quantizer: three
+    bf16 piece products per fp32 product on the bf16 matrix cores) `exec_flops` / `peak` say what ran and against which peak."""
     ep = C * T * 4
     fft_flops = 2 * 5.0 * fft_n * np.log2(fft_n) + 6.0 * fft_n       # forward + inverse complex FFT + spectrum product, per row
     return {
@@ -61,9 +65,12 @@ def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False):
         "bandpower": dict(flops=0.0, bytes=(C * F * 4 + 24) * E, bound="hbm"),
         "conv1": dict(flops=2.0 * 64 * C * 4 * L1 * E, bytes=(ep + 64 * L1 * 4) * E, bound="mfma"),
         "conv2": dict(flops=2.0 * 128 * 64 * 4 * S * E, bytes=(64 * L1 * 4 + 128 * S * 4) * E, bound="mfma"),
-        "conv3": dict(flops=2.0 * 256 * 128 * 3 * S * E, bytes=(128 * S * 4 + 256 * S * 4) * E, bound="mfma"),
+        "conv3": dict(flops=2.0 * 256 * 128 * 3 * S * E, exec_flops=2.0 * 256 * 128 * 2 * S * E, bytes=(128 * S * 4 + 256 * S * 4) * E,
+                      bound="mfma"),
         "conv4": dict(flops=2.0 * D * 256 * S * E, bytes=(256 * S * 4 + D * S * 4) * E, bound="mfma"),
-        "vq": dict(flops=2.0 * S * K * D * E, bytes=(D * S * 4 + S * 8) * E, bound="mfma"),
+        "vq": dict(flops=2.0 * S * K * D * E, bytes=(D * S * 4 + S * 8) * E, bound="mfma",
+                   **({"exec_flops": {"screen": 3.0, "bf16x6": 6.0}[vq_method] * 2.0 * S * K * D * E, "peak": PEAK_BF16_TFLOPS}
+                      if vq_method in ("screen", "bf16x6") else {})),
     }
 
 
@@ -77,6 +84,12 @@ def stage_report(acc, model):
         gb = mod["bytes"] / (m * 1e-3) / 1e9
         stages[name] = {"ms": round(m, 4), "bound": mod["bound"], "tflops": round(tf, 3), "gbs": round(gb, 1),
                         "frac": round(tf / PEAK_FP32_TFLOPS if mod["bound"] == "mfma" else gb / PEAK_HBM_GBS, 4)}
+        if "exec_flops" in mod:     # what the kernel executed, against the peak of the unit it ran on
+            et = mod["exec_flops"] / (m * 1e-3) / 1e12
+            peak = mod.get("peak", PEAK_FP32_TFLOPS)
+            stages[name].update(executed_tflops=round(et, 3), executed_peak=peak, executed_frac=round(et / peak, 4))
+            if "peak" in mod:       # a different unit than the fp32 matrix peak: `frac` is the executed fraction there
+                stages[name]["frac"] = round(et / peak, 4)
     return stages
 
 
@@ -239,8 +252,11 @@ def parse_args(argv=None):
                          "on a copy stream overlap the kernels of chunk i)")
     ap.add_argument("--emit-cleaned", action="store_true",
                     help="also write the baseline-corrected epochs (+180 000 B/epoch; not among SURVEY.md 8(d)'s compulsory outputs)")
-    ap.add_argument("--vq", choices=["fp32", "bf16x6"], default="fp32",
-                    help="codebook argmin kernel: fp32 MFMA (default) or fp32 products from three bf16 pieces on the bf16 MFMA")
+    ap.add_argument("--vq", choices=["screen", "fp32", "bf16x6"], default="screen",
+                    help="codebook argmin: 'screen' (default) = the fp32 search's tokens, bit for bit, from a bf16 screening pass with a "
+                         "rigorous error bound + the fp32 kernel on the rows it cannot settle (checked against the fp32 search on a "
+                         "whole chunk in every run: screen_check); 'fp32' = the fp32-MFMA search on every row; 'bf16x6' = fp32 products "
+                         "from three bf16 pieces (near-tie rule)")
     ap.add_argument("--conv", choices=["fp32", "bf16x6"], default="fp32",
                     help="256-channel encoder layers: fp32 MFMA kernels (default) or the three-bf16-piece implicit GEMM")
     ap.add_argument("--no-fold-proj", dest="fold_proj", action="store_false",
@@ -440,7 +456,7 @@ def run_rank(args):
     # room left beside the resident input: allocator slack, RCCL's buffers and (N > 1) the flattened receive buffers torch
     # stages one group of each array through before it scatters them to the [w, lo:hi] slices
     reserve = 6 << 30
-    run_variants = rank == 0 and args.shape == "S" and args.fold_proj and args.vq == "fp32" and args.conv == "fp32"
+    run_variants = rank == 0 and args.shape == "S" and args.fold_proj and args.vq == "screen" and args.conv == "fp32"
     z_var = None
     if run_variants:      # the unfolded variants write z: take that buffer before the resident input claims the rest of the HBM
         z_var = torch.empty((chunk, D, pipe.P2), dtype=torch.float32, device=dev)
@@ -559,14 +575,35 @@ def run_rank(args):
             acc.setdefault(name, []).append(s_.elapsed_time(e_))
         pipe.stage_events = None
         fft_n = 2048 if args.shape == "S" else 3 * 4096
-        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned)
+        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned, vq_method=args.vq)
         stages = stage_report(acc, model)
+
+    # the screened quantizer against the fp32 search it stands for: one whole chunk, every token (outside the timed region)
+    screen_check = None
+    if rank == 0 and args.vq == "screen":
+        kw = dict(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, conv_method=args.conv,
+                  fold_projection=args.fold_proj)
+        ref_pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(vq_method="fp32", **kw), taps, A, b, weights, codebook, device=dev)
+        ref_pipe._buf, ref_pipe._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z too, if unfolded)
+        pipe.reset_hist()
+        got = pipe.run(x[:chunk])
+        tok_s, hist_s = got["tokens"].clone(), got["hist"].clone()
+        refined = int(pipe._buf["vq_ws"][:4].view(torch.int32).item())
+        ref_pipe._buf["tokens"] = torch.empty_like(pipe._buf["tokens"])
+        ref_pipe._buf["hist"] = torch.zeros_like(pipe._buf["hist"])
+        want = ref_pipe.run(x[:chunk])
+        torch.cuda.synchronize()
+        screen_check = {"rows": int(tok_s.numel()), "tokens_equal_fp32_search": bool(torch.equal(tok_s, want["tokens"])),
+                        "hist_equal": bool(torch.equal(hist_s, want["hist"])), "rows_searched_in_fp32": refined,
+                        "fraction_searched_in_fp32": round(refined / tok_s.numel(), 5)}
+        del ref_pipe, tok_s, hist_s
 
     # non-default variants of the tokenizer tail, same chunk, outside the timed region (reported, never `value`)
     variants = {}
     if run_variants:
         base_ms = sum(v["ms"] for v in stages.values())
-        for name, kw in (("fp32_unfolded_projection", dict(fold_projection=False)),
+        for name, kw in (("fp32_search_of_every_row", dict(vq_method="fp32", fold_projection=True)),
+                         ("fp32_unfolded_projection", dict(vq_method="fp32", fold_projection=False)),
                          ("vq_bf16x6", dict(vq_method="bf16x6")),
                          ("vq_bf16x6+conv_bf16x6", dict(vq_method="bf16x6", conv_method="bf16x6")),
                          ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True)),
@@ -594,11 +631,15 @@ def run_rank(args):
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # HBM bytes per launch from rocprofv3 --pmc passes
         if os.path.exists(tpath) and args.shape == "S" and chunk == 16384 and K == 512:   # counters were taken on that launch
             with open(tpath) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+                tkey = dom if (dom != "vq" or args.vq == "fp32") else "vq_" + args.vq
+                traffic = json.load(f).get(tkey, {}).get("hbm_bytes_per_launch")
         m = model[dom]
         key, peak, unit = ("tflops", PEAK_FP32_TFLOPS, "TFLOP/s") if m["bound"] == "mfma" else ("gbs", PEAK_HBM_GBS, "GB/s")
-        roof = {"kernel": KERNEL_OF_STAGE.get(dom, dom), "bound": m["bound"], "achieved": stages[dom][key], "peak": peak, "unit": unit,
-                "frac": round(stages[dom][key] / peak, 4), "traffic": traffic,
+        if m["bound"] == "mfma" and "peak" in m:      # ran on another unit than the fp32 matrix cores: executed flops against its peak
+            key, peak = "executed_tflops", m["peak"]
+        roof = {"kernel": KERNEL_OF_VQ[args.vq] if dom == "vq" else KERNEL_OF_STAGE.get(dom, dom), "bound": m["bound"],
+                "achieved": stages[dom][key], "peak": peak, "unit": unit,
+                "frac": round(stages[dom][key] / peak, 4), "executed_frac": stages[dom].get("executed_frac"), "traffic": traffic,
                 "traffic_source": "stored counter run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, "
                                   "profiles/pmc_traffic.json), not measured in this process" if traffic is not None else None,
                 "launch": f"{chunk} epochs, {stages[dom]['ms']} ms"}
@@ -633,6 +674,7 @@ def run_rank(args):
             "roofline": roof,
             "cpu_baseline": cpu,
             "stages": stages,
+            "screen_check": screen_check,
             "gather_ms_per_step": gather_ms,
             "gather_bytes_per_rank": (xch.bytes_per_epoch() * E) if xch is not None else None,
             "gather_order_ok": gather_ok,

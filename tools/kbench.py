@@ -71,7 +71,7 @@ def main():
         y = torch.empty_like(x)
     if s in ("ica_stats",):
         pass
-    elif s in ("vq", "vqb"):
+    elif s in ("vq", "vqb", "vqs"):
         PS = (S + 3) & ~3
         z = rnd(E, 256, PS)
         cb = w["vq_layer.embedding.weight"].contiguous()
@@ -79,6 +79,10 @@ def main():
         lib.lbm_rownorm2_f32(p(cb), p(ee), 512, 256, st)
         tok = torch.empty(E, S, dtype=torch.int64, device=dev)
         fn = lambda: lib.lbm_vq_argmin_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
+        if s == "vqs":      # screened search (on random rows nearly nothing needs the fp32 pass; bench.py reports the real fraction)
+            tab = lbm_amd.vq_split_tables(cb)
+            ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(E * S), dtype=torch.uint8, device=dev)
+            fn = lambda: lib.lbm_vq_argmin_screened_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(tab), p(ee), p(tok), None, p(ws), E * S, 256, 512, st)  # noqa: E731
         if s == "vqb":
             tab = lbm_amd.vq_split_tables(cb)
             fn = lambda: lib.lbm_vq_argmin_bf16x6_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(tab), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
@@ -147,7 +151,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.reps
     extra = ""
-    if s in ("vq", "vqb"):
+    if s in ("vq", "vqb", "vqs"):
         extra = f", {2.0 * 512 * 256 * 375 * E / (ms * 1e-3) / 1e12:.1f} fp32-equivalent TFLOP/s"
     if s.startswith("conv"):
         extra = f", {2.0 * cout * cin * ks * lout * E / (ms * 1e-3) / 1e12:.1f} TFLOP/s"
