@@ -289,10 +289,10 @@ int lbm_vq_argmin_bf16x6_f32(const float* x, int64_t ldx, int32_t layout, int64_
  * (csrc/vq_screen.hip derives it); a row whose best code's upper bound lies below every other code's lower bound is settled.
  * Pass 2 re-searches the remaining rows (1-2 % on the shipped codebooks; exact duplicates of a code row always) with
  * lbm_vq_argmin_f32's own kernel code.  tables: lbm_vq_split_tables_init(codebook) (above); codebook / e_sqnorm / layout /
- * hist_or_null as for lbm_vq_argmin_f32 (no minimum-distance output).  workspace: lbm_vq_screen_workspace_bytes(N) bytes of
+ * hist_or_null as for lbm_vq_argmin_f32 (no minimum-distance output).  workspace: lbm_vq_screen_workspace_bytes(N, K) bytes of
  * caller-owned, 8-byte aligned device memory; after the call its first int32 holds the number of rows pass 2 searched.
  * D a multiple of 8 and <= 256, N < 2^31. */
-size_t lbm_vq_screen_workspace_bytes(int64_t N);
+size_t lbm_vq_screen_workspace_bytes(int64_t N, int32_t K);
 int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const float* codebook, const void* tables,
                                const float* e_sqnorm, int64_t* idx_out, unsigned long long* hist_or_null, void* workspace,
                                int64_t N, int32_t D, int32_t K, lbm_stream_t stream);

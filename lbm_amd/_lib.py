@@ -59,7 +59,7 @@ SIGNATURES = {
     "lbm_vq_split_tables_bytes": (C.c_size_t, [_i32, _i32]),
     "lbm_vq_split_tables_init": (C.c_int, [_p, _p, _i32, _i32, _p]),
     "lbm_vq_argmin_bf16x6_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
-    "lbm_vq_screen_workspace_bytes": (C.c_size_t, [_i64]),
+    "lbm_vq_screen_workspace_bytes": (C.c_size_t, [_i64, _i32]),
     "lbm_vq_argmin_screened_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_vq_gather_loss_f32": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "lbm_vq_ema_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),

@@ -32,18 +32,21 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& p1, bf16x8& p2, b
     }
 }
 
-// Pre-split codebook table of the quantizer kernels: [nst][3][Kp][16] bf16 pieces, then float en[Kp] = an upper bound of |e_k|
-// (the screening kernel's error bound; the six-product kernel does not read it).
+// Pre-split codebook table of the quantizer kernels:
+//   [nst][3][Kp][16] bf16 pieces in k-stages of 16 (the six-product kernel's LDS image order),
+//   float en[Kp]  = an upper bound of |e_k| (0 beyond K)                      -- the screening kernel's error bound
+//   [Kp][2][256] bf16 = per code its first two pieces over all (zero padded) dims, 1 KiB per code   -- the screening kernel's tiles
 struct VqTabPlan {
     int Kp, nst;
-    size_t piece_bytes, bytes;
+    size_t piece_bytes, rows_off, bytes;
 };
 inline VqTabPlan vq_tab_plan(int K, int D) {
     VqTabPlan p;
     p.Kp = (K + kSup - 1) / kSup * kSup;
     p.nst = (D + kKC - 1) / kKC;
     p.piece_bytes = (size_t)p.nst * 3 * p.Kp * 32;
-    p.bytes = p.piece_bytes + (size_t)p.Kp * sizeof(float);
+    p.rows_off = p.piece_bytes + (size_t)p.Kp * sizeof(float);
+    p.bytes = p.rows_off + (size_t)p.Kp * 1024;
     return p;
 }
 

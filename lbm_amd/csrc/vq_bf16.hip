@@ -42,6 +42,24 @@ __global__ __launch_bounds__(256) void vq_split_tables_kernel(const float* __res
     for (int q = 0; q < 3; ++q) tab[(((int64_t)st * 3 + q) * Kp + code) * 2 + (half ^ ((code >> 3) & 1))] = p[q];   // LDS image order
 }
 
+// rows[code][piece][256] bf16: the first two pieces of every code over all dims (zero beyond D and K); thread = (code, octet)
+__global__ __launch_bounds__(256) void vq_rows_table_kernel(const float* __restrict__ codebook, bf16x8* __restrict__ rows, int K, int Kp,
+                                                            int D) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Kp * 32) return;
+    const int code = (int)(i >> 5), oct = (int)(i & 31);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int d = oct * 8 + e;
+        v[e] = (code < K && d < D) ? codebook[(int64_t)code * D + d] : 0.f;
+    }
+    bf16x8 p1, p2, p3;
+    split8(v, p1, p2, p3);
+    rows[(int64_t)code * 64 + oct] = p1;
+    rows[(int64_t)code * 64 + 32 + oct] = p2;
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(kThreads, 2) void vq_bf16x6_kernel(const float* __restrict__ x, int64_t ldx, const u32x4* __restrict__ tab,
                                                                 const float* __restrict__ e_sqnorm, int64_t* __restrict__ idx_out,
@@ -306,6 +324,8 @@ extern "C" int lbm_vq_split_tables_init(void* tables, const float* codebook, int
                        static_cast<bf16x8*>(tables), K, p.Kp, D, p.nst);
     hipLaunchKernelGGL(vq_code_norms_kernel, dim3((unsigned)((p.Kp + 255) / 256)), dim3(256), 0, lbm::as_stream(stream), codebook,
                        reinterpret_cast<float*>(static_cast<unsigned char*>(tables) + p.piece_bytes), K, p.Kp, D);
+    hipLaunchKernelGGL(vq_rows_table_kernel, dim3((unsigned)((p.Kp * 32 + 255) / 256)), dim3(256), 0, lbm::as_stream(stream), codebook,
+                       reinterpret_cast<bf16x8*>(static_cast<unsigned char*>(tables) + p.rows_off), K, p.Kp, D);
     return lbm::check_launch("lbm_vq_split_tables_init");
 }
 

@@ -139,7 +139,7 @@ class EpochPipeline:
             if not c.fold_projection:
                 B.update(z=mk(E, self.D, self.P2))
             if c.vq_method == "screen":
-                B.update(vq_ws=mk(int(self.lib.lbm_vq_screen_workspace_bytes(E * self.S)), dt=torch.uint8))
+                B.update(vq_ws=mk(int(self.lib.lbm_vq_screen_workspace_bytes(E * self.S, self.K)), dt=torch.uint8))
         self._buf, self._cap = B, E
 
     def reset_hist(self):

@@ -103,7 +103,7 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
         if split_tables is None or return_min:
             raise ValueError("screened=True needs split_tables and has no minimum-distance output")
         lib = _lib.load()
-        ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(N), dtype=torch.uint8, device=x.device)
+        ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(N, K), dtype=torch.uint8, device=x.device)
         _lib.check(lib.lbm_vq_argmin_screened_f32(_lib.ptr(x), ldx, layout, S, _lib.ptr(cb), _lib.ptr(split_tables), _lib.ptr(e_sqnorm),
                                                   _lib.ptr(idx), _lib.ptr(hist), _lib.ptr(ws), N, D, K, _lib.stream_ptr()),
                    "lbm_vq_argmin_screened_f32")

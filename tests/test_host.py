@@ -113,7 +113,7 @@ def test_argument_validation_without_launch():
     assert b"larger than the number of samples" in lib.lbm_last_error()
     assert lib.lbm_welch_tables_bytes(500, 500, 4, 30) >= 64 + 4 * 1500
     # the bf16-piece entry points and the resampler
-    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 + 512 * 4 and lib.lbm_vq_split_tables_bytes(512, 300) == 0
+    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 + 512 * 4 + 512 * 1024 and lib.lbm_vq_split_tables_bytes(512, 300) == 0
     assert lib.lbm_conv1d_split_tables_bytes(128, 256, 3) == 24 * 3 * 256 * 32
     assert lib.lbm_conv1d_split_tables_bytes(30, 64, 4) == 8 * 3 * 256 * 32            # Cin -> 32, Cout -> 256
     assert lib.lbm_conv1d_split_tables_bytes(5000, 64, 4) == 0
@@ -148,10 +148,10 @@ def test_lds_dma_kernels_do_not_spill():
 
 def test_vq_screen_workspace_and_arguments():
     lib = _lib.load()
-    assert lib.lbm_vq_screen_workspace_bytes(0) == 256
-    assert lib.lbm_vq_screen_workspace_bytes(1000) == 256 + 8000
-    assert lib.lbm_vq_screen_workspace_bytes(-1) == 0
-    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 + 512 * 4      # pieces + the code-norm tail
+    assert lib.lbm_vq_screen_workspace_bytes(0, 512) == 256 + 2048
+    assert lib.lbm_vq_screen_workspace_bytes(1000, 300) == 256 + 2048 + 8000
+    assert lib.lbm_vq_screen_workspace_bytes(-1, 512) == 0
+    assert lib.lbm_vq_split_tables_bytes(512, 256) == 16 * 3 * 512 * 32 + 512 * 4 + 512 * 1024      # pieces + the code-norm tail
     # argument validation happens before any launch
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 0, 256, 512, None) == 0   # N == 0
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1

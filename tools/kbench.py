@@ -81,7 +81,7 @@ def main():
         fn = lambda: lib.lbm_vq_argmin_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
         if s == "vqs":      # screened search (on random rows nearly nothing needs the fp32 pass; bench.py reports the real fraction)
             tab = lbm_amd.vq_split_tables(cb)
-            ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(E * S), dtype=torch.uint8, device=dev)
+            ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(E * S, 512), dtype=torch.uint8, device=dev)
             fn = lambda: lib.lbm_vq_argmin_screened_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(tab), p(ee), p(tok), None, p(ws), E * S, 256, 512, st)  # noqa: E731
         if s == "vqb":
             tab = lbm_amd.vq_split_tables(cb)

@@ -19,12 +19,12 @@ xd, cbd = torch.from_numpy(x).to(dev), torch.from_numpy(cb).to(dev)
 tab = lbm_amd.vq_split_tables(cbd)
 lib = _lib.load()
 ee = lbm_amd.quantizer.rownorm2(cbd)
-ws = torch.zeros(lib.lbm_vq_screen_workspace_bytes(N), dtype=torch.uint8, device=dev)
+ws = torch.zeros(lib.lbm_vq_screen_workspace_bytes(N, K), dtype=torch.uint8, device=dev)
 idx = torch.empty(N, dtype=torch.int64, device=dev)
 rc = lib.lbm_vq_argmin_screened_f32(_lib.ptr(xd), D, 0, 0, _lib.ptr(cbd), _lib.ptr(tab), _lib.ptr(ee), _lib.ptr(idx), None, _lib.ptr(ws), N, D, K, _lib.stream_ptr())
 torch.cuda.synchronize()
 n = int(ws[:4].view(torch.int32).item())
-lst = ws[256:256 + 8 * n].view(torch.int64).cpu().numpy()
+lst = ws[256 + 2048:256 + 2048 + 8 * n].view(torch.int64).cpu().numpy()
 print("rc", rc, "refined", n, "listed among midpoints", np.sum(lst < q), "others", np.sum(lst >= q))
 ref = lbm_amd.vq_argmin(xd, cbd)
 print("equal", bool(torch.equal(ref, idx)), "ref tokens of first midpoints", ref[:6].tolist(), "pairs", list(zip(i0[:6].tolist(), i1[:6].tolist())))

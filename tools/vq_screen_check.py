@@ -34,7 +34,7 @@ for fold in (True, False):
         res[m] = (out["tokens"].clone(), ms["vq"])
         if m == "screen":
             nref = int(pipe._buf["vq_ws"][:4].view(torch.int32).item())
-            listed = pipe._buf["vq_ws"][256:256 + 8 * nref].view(torch.int64).clone()
+            listed = pipe._buf["vq_ws"][256 + 2048:256 + 2048 + 8 * nref].view(torch.int64).clone()
         del pipe
     same = bool(torch.equal(res["fp32"][0], res["screen"][0]))
     ok &= same
