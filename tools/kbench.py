@@ -79,10 +79,21 @@ def main():
         lib.lbm_rownorm2_f32(p(cb), p(ee), 512, 256, st)
         tok = torch.empty(E, S, dtype=torch.int64, device=dev)
         fn = lambda: lib.lbm_vq_argmin_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
-        if s == "vqs":      # screened search (on random rows nearly nothing needs the fp32 pass; bench.py reports the real fraction)
-            tab = lbm_amd.vq_split_tables(cb)
-            ws = torch.empty(lib.lbm_vq_screen_workspace_bytes(E * S, 512), dtype=torch.uint8, device=dev)
-            fn = lambda: lib.lbm_vq_argmin_screened_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(cb), p(tab), p(ee), p(tok), None, p(ws), E * S, 256, 512, st)  # noqa: E731
+        if s == "vqs":      # screened search of the folded codebook on the encoder's own activations (random rows would all tie)
+            taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+            A, b = lbm_amd.ica_projection(**synth_ica(C))
+            with np.load(os.path.join(ROOT, "tests", "golden", "vq_vae_shipped.npz")) as f:
+                shipped = {k: f[k] for k in f.files}
+            cfgp = lbm_amd.PipelineConfig(sfreq=500.0, n_channels=C, n_times=T, n_baseline=251, emit_cleaned=False, fold_projection=True,
+                                          vq_method="screen")
+            pipe = lbm_amd.EpochPipeline(cfgp, taps, A, b, shipped, shipped["vq_layer.embedding.weight"], device=dev)
+            xe = synth_epochs(E, C, T, seed=3, device=dev, chunk=2048)
+            pipe.run(xe)
+            torch.cuda.synchronize()
+            del xe
+            h3, ws, tok = pipe._buf["h3"], pipe._buf["vq_ws"], pipe._buf["tokens"]
+            fn = lambda: lib.lbm_vq_argmin_screened_f32(p(h3), pipe.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, S, p(pipe.cb_fold), p(pipe.vq_tab),  # noqa: E731
+                                                        p(pipe.ee_fold), p(tok), None, p(ws), E * S, 256, 512, st)
         if s == "vqb":
             tab = lbm_amd.vq_split_tables(cb)
             fn = lambda: lib.lbm_vq_argmin_bf16x6_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(tab), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
