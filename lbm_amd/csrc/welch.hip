@@ -243,6 +243,9 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
             const int sg = sg0 + (lane >> 2), part = lane & 3;
             const int sgc = sg < nsegs ? sg : nsegs - 1;
             const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
+            // the mean is kept as first sample + mean of the differences to it: rows with an offset far above the signal keep
+            // their signal bits (s_mean holds the second term)
+            const float b0 = base[0];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int n = 8 * part;
             if (((T | g.hop) & 1) == 0) {   // 8-byte aligned segments: half the LDS instructions
@@ -252,27 +255,27 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
                     for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float2*>(base + n + 32 * (u >> 2) + 2 * (u & 3));
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        acc[2 * (u & 3)] += v[u].x;
-                        acc[2 * (u & 3) + 1] += v[u].y;
+                        acc[2 * (u & 3)] += v[u].x - b0;
+                        acc[2 * (u & 3) + 1] += v[u].y - b0;
                     }
                 }
                 for (; n + 8 <= g.N; n += 32) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float2 v = *reinterpret_cast<const float2*>(base + n + 2 * u);
-                        acc[2 * u] += v.x;
-                        acc[2 * u + 1] += v.y;
+                        acc[2 * u] += v.x - b0;
+                        acc[2 * u + 1] += v.y - b0;
                     }
                 }
             } else {
                 for (; n + 8 <= g.N; n += 32) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc[u] += base[n + u];
+                    for (int u = 0; u < 8; ++u) acc[u] += base[n + u] - b0;
                 }
             }
             if (n < g.N) {   // ragged tail group of this lane
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += (n + u < g.N) ? base[n + u] : 0.f;
+                for (int u = 0; u < 8; ++u) acc[u] += (n + u < g.N) ? base[n + u] - b0 : 0.f;
             }
             float sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
             sum += __shfl_xor(sum, 1, 64);
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
             const int sg = tile * 16 + j;
             const int sgc = sg < nsegs ? sg : 0;
             const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
-            const float m = s_mean[sgc];
+            const float m = s_mean[sgc], b0 = base[0];   // every sample enters as (d - first sample) - m
             const float* bb = s_basis + j * g.LDB;
             f32x4 acc[4];   // re_e, im_e, re_o, im_o
 #pragma unroll
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
                 return o;
             };
             auto step_generic = [&](const Ops& cur) {
-                const float d1 = cur.d1 - m, d3 = cur.d3 - m;
-                float d2 = cur.d2 - m, d4 = cur.d4 - m;
+                const float d1 = (cur.d1 - b0) - m, d3 = (cur.d3 - b0) - m;
+                float d2 = (cur.d2 - b0) - m, d4 = (cur.d4 - b0) - m;
                 if (cur.nc == 0) { d2 = 0.f; d4 = 0.f; }
                 const float a1 = cur.w1 * (d1 + d2), a2 = cur.w2 * (d3 + d4);
                 const float b1 = cur.w1 * (d1 - d2), b2 = cur.w2 * (d3 - d4);
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
             struct Fast { float d1, d2, d3, d4, w1, w2; float4 bs; };
             const float m2 = 2.f * m;
             auto step_fast = [&](const Fast& o) {
-                const float a1 = o.w1 * ((o.d1 + o.d2) - m2), a2 = o.w2 * ((o.d3 + o.d4) - m2);
+                const float a1 = o.w1 * (((o.d1 - b0) + (o.d2 - b0)) - m2), a2 = o.w2 * (((o.d3 - b0) + (o.d4 - b0)) - m2);
                 const float b1 = o.w1 * (o.d1 - o.d2), b2 = o.w2 * (o.d3 - o.d4);
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1 + a2, o.bs.x, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1 - b2, o.bs.y, acc[1], 0, 0, 0);
@@ -414,7 +417,8 @@ __global__ __launch_bounds__(384) void welch_fold_kernel(const float* __restrict
 // owner wave, in ascending wave order; the segment average and the store are spread over the team.  Where the per-segment
 // mean cannot reach the requested bins (table header flag: full-length Hann / Hamming and bin_lo >= 2, boxcar and bin_lo >= 1)
 // the means phase is gone: the fold subtracts the segment's FIRST SAMPLE instead (any constant is annihilated exactly there;
-// this one keeps the sums well conditioned for rows with a large offset).
+// this one keeps the sums well conditioned for rows with a large offset).  Where it is needed, the mean is carried as first
+// sample + mean of the differences to it.
 constexpr int kTeamSteps = 16;  // k-steps per wave held in registers (QS / TS rounded up must not exceed it)
 
 __host__ __device__ inline int team_rows_pad(int rows_floats) { return (rows_floats + 255) & ~255; }   // whole 1 KiB DMA units
@@ -491,8 +495,9 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
                 const int sg = sg0 + (lane >> 2), part = lane & 3;
                 const int sgc = sg < nsegs ? sg : nsegs - 1;
                 const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
-                float sum = 0.f;
-                for (int n = part; n < g.N; n += 4) sum += base[n];
+                const float b0 = base[0];      // the mean is kept as first sample + mean of the differences: rows with an offset
+                float sum = 0.f;               // far above the signal keep their signal bits
+                for (int n = part; n < g.N; n += 4) sum += base[n] - b0;
                 sum += __shfl_xor(sum, 1, 64);
                 sum += __shfl_xor(sum, 2, 64);
                 if (part == 0 && sg < nsegs) s_mean[sg] = sum * inv_n;
@@ -510,8 +515,11 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
             const int sg = tile * 16 + j;
             const int sgc = sg < nsegs ? sg : 0;
             const float* base = s_rows + (sgc / g.nseg) * T + (sgc % g.nseg) * g.hop;
-            const float m = mean_free ? base[0] : s_mean[sgc];
-            const float m2 = 2.f * m;
+            // every sample enters as (d - first sample) - r, r = mean of those differences (0 where the mean cannot reach the
+            // requested bins): differences of neighbouring samples are (nearly) exact, whatever the row's offset
+            const float b0 = base[0];
+            const float rm = mean_free ? 0.f : s_mean[sgc];
+            const float m2 = 2.f * rm;
             f32x4 acc[4];
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -522,9 +530,9 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
             auto generic = [&](int t, const float4 bs) {
                 const int n = 4 * t + kqv;
                 const int nc = n < g.Q ? n : g.Q;
-                const float d1 = base[nc] - m, d3 = base[g.H - nc] - m;
-                float d2 = base[g.N - (nc ? nc : 1)] - m;   // d[N - n]; d[N] does not exist
-                float d4 = base[g.H + nc] - m;              // d[H + n]; at n == 0 it is d[H] again
+                const float d1 = (base[nc] - b0) - rm, d3 = (base[g.H - nc] - b0) - rm;
+                float d2 = (base[g.N - (nc ? nc : 1)] - b0) - rm;   // d[N - n]; d[N] does not exist
+                float d4 = (base[g.H + nc] - b0) - rm;              // d[H + n]; at n == 0 it is d[H] again
                 if (nc == 0) { d2 = 0.f; d4 = 0.f; }
                 const float w1 = n <= g.Q ? s_win[nc] : 0.f, w2 = n <= g.Q ? s_win[g.H - nc] : 0.f;   // k-slots past the middle term
                 const float a1 = w1 * (d1 + d2), a2 = w2 * (d3 + d4);
@@ -546,9 +554,9 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
                 o.da.x = p1[4 * st]; o.db.y = p4[4 * st]; o.da.y = p3[-4 * st]; o.db.x = p2[-4 * st];
                 return o;
             };
-            const f32x2 m2v = {m2, m2};
+            const f32x2 m2v = {m2, m2}, b0v = {b0, b0};
             auto fast = [&](const Ld& o, const f32x2 w, const float4 bs) {
-                const f32x2 a = w * ((o.da + o.db) - m2v);  // {a1, a2}
+                const f32x2 a = w * (((o.da - b0v) + (o.db - b0v)) - m2v);  // {a1, a2}
                 const f32x2 b = w * (o.da - o.db);          // {b1, b2}
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x + a.y, bs.x, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x - b.y, bs.y, acc[1], 0, 0, 0);

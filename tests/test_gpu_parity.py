@@ -215,6 +215,20 @@ def test_welch_matches_oracle(T, fs, nfft, nov, win, fmin, fmax):
     assert _psd_err(psd.cpu().numpy(), want) <= 1.0
 
 
+@pytest.mark.parametrize("rows,T,fs,nfft,fmin", [(7, 1500, 500.0, 500, 4.0), (3, 10000, 1000.0, 1000, 4.0), (5, 1500, 500.0, 500, 0.0),
+                                               (4, 1502, 500.0, 500, 4.0), (1, 1001, 500.0, 500, 2.0)])
+def test_welch_team_kernel_offsets_and_ragged_groups(rows, T, fs, nfft, fmin):
+    """The team kernel (round 2): rows with a DC offset 1000x the signal (the mean-free path subtracts the segment's first sample
+    instead of its mean: exact where the window annihilates constants), row counts that leave a ragged last group, bins that
+    include DC (per-segment means are computed again), and a row length the team path does not take (T % 4 != 0)."""
+    x = synth_epochs(1, rows, T, sfreq=fs, seed=81)[0]
+    x = x + torch.linspace(-1.0, 1.0, rows).unsqueeze(1) * 2e-2
+    psd, freqs = lbm_amd.psd_array_welch(x.to(DEV), fs, fmin, 30.0, n_fft=nfft, n_overlap=nfft // 2, window="hann")
+    want, wf = orc.welch_psd(x.numpy().astype(np.float64), fs, fmin, 30.0, n_fft=nfft, n_overlap=nfft // 2, window="hann")
+    assert np.array_equal(freqs, wf) and psd.shape == want.shape
+    assert _psd_err(psd.cpu().numpy(), want) <= 1.0
+
+
 def test_welch_average_modes_and_errors():
     x = synth_epochs(2, 3, 1500, seed=9)
     xd = x.to(DEV)
