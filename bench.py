@@ -268,6 +268,9 @@ def parse_args(argv=None):
                          "rigorous error bound + the fp32 kernel on the rows it cannot settle (checked against the fp32 search on a "
                          "whole chunk in every run: screen_check); 'fp32' = the fp32-MFMA search on every row; 'bf16x6' = fp32 products "
                          "from three bf16 pieces (near-tie rule)")
+    ap.add_argument("--screen-check-chunks", type=int, default=0,
+                    help="--vq screen: how many chunks of the job are re-tokenized with the fp32 search and compared token by token "
+                         "(outside the timed region); 0 = all of them")
     ap.add_argument("--conv", choices=["fp32", "bf16x6"], default="fp32",
                     help="256-channel encoder layers: fp32 MFMA kernels (default) or the three-bf16-piece implicit GEMM")
     ap.add_argument("--no-fold-proj", dest="fold_proj", action="store_false",
@@ -589,25 +592,35 @@ def run_rank(args):
         model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned, vq_method=args.vq)
         stages = stage_report(acc, model)
 
-    # the screened quantizer against the fp32 search it stands for: one whole chunk, every token (outside the timed region)
+    # the screened quantizer against the fp32 search it stands for: EVERY token of one whole step (all chunks of the job, walked as
+    # the timed step walks them), outside the timed region
     screen_check = None
     if rank == 0 and args.vq == "screen":
         kw = dict(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, conv_method=args.conv,
                   fold_projection=args.fold_proj)
         ref_pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(vq_method="fp32", **kw), taps, A, b, weights, codebook, device=dev)
         ref_pipe._buf, ref_pipe._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z too, if unfolded)
-        pipe.reset_hist()
-        got = pipe.run(x[:chunk])
-        tok_s, hist_s = got["tokens"].clone(), got["hist"].clone()
-        refined = int(pipe._buf["vq_ws"][:4].view(torch.int32).item())
         ref_pipe._buf["tokens"] = torch.empty_like(pipe._buf["tokens"])
         ref_pipe._buf["hist"] = torch.zeros_like(pipe._buf["hist"])
-        want = ref_pipe.run(x[:chunk])
+        pipe.reset_hist()
+        n_chunks_checked = nchunks if args.screen_check_chunks <= 0 else min(nchunks, args.screen_check_chunks)
+        rows = refined = differ = 0
+        for i in range(n_chunks_checked):
+            lo = i * chunk
+            n = min(chunk, E - lo)
+            src = lo % R
+            if src + n > R:
+                src = R - n
+            got = pipe.run(x[src:src + n])
+            refined += int(pipe._buf["vq_ws"][:4].view(torch.int32).item())
+            want = ref_pipe.run(x[src:src + n])
+            differ += int((got["tokens"] != want["tokens"]).sum().item())
+            rows += got["tokens"].numel()
         torch.cuda.synchronize()
-        screen_check = {"rows": int(tok_s.numel()), "tokens_equal_fp32_search": bool(torch.equal(tok_s, want["tokens"])),
-                        "hist_equal": bool(torch.equal(hist_s, want["hist"])), "rows_searched_in_fp32": refined,
-                        "fraction_searched_in_fp32": round(refined / tok_s.numel(), 5)}
-        del ref_pipe, tok_s, hist_s
+        screen_check = {"chunks": n_chunks_checked, "rows": rows, "tokens_differing_from_fp32_search": differ,
+                        "tokens_equal_fp32_search": differ == 0, "hist_equal": bool(torch.equal(pipe._buf["hist"], ref_pipe._buf["hist"])),
+                        "rows_searched_in_fp32": refined, "fraction_searched_in_fp32": round(refined / max(rows, 1), 5)}
+        del ref_pipe
 
     # non-default variants of the tokenizer tail, same chunk, outside the timed region (reported, never `value`)
     variants = {}

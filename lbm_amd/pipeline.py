@@ -237,8 +237,8 @@ class EpochPipeline:
             conv(B["h2"], self.P2, B["h3"], self.P2, 4, 128, self.L2, 256, 3, 1, 1, 1)
             t0 = mark("conv3", t0)
             vq = lib.lbm_vq_argmin_f32 if self.vq_tab is None else lib.lbm_vq_argmin_bf16x6_f32
-            if c.vq_method == "screen":
-                def vq(x_, ldx_, layout_, S_, cb_or_tab, ee_, tok_, _mind, hist_, N_, D_, K_, st_, cb=None):
+            if c.vq_method == "screen":      # same call shape as the other two; needs the fp32 codebook AND its piece table
+                def vq(x_, ldx_, layout_, S_, _table, ee_, tok_, _mind, hist_, N_, D_, K_, st_):
                     cb = self.cb_fold if c.fold_projection else self.codebook
                     return lib.lbm_vq_argmin_screened_f32(x_, ldx_, layout_, S_, p(cb), p(self.vq_tab), ee_, tok_, hist_, p(B["vq_ws"]),
                                                           N_, D_, K_, st_)
