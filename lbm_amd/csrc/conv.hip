@@ -149,8 +149,9 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < Cfg::A_F4; ++i) {
             asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
-            const bool ok = a_ok[i] && a_k[i] >= shift;
-            *reinterpret_cast<float4*>(sa + a_lds[i]) = ok ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            // (rows past Cout hold row 0's weights: their outputs are never stored, so they need no mask)
+            if (shift == 0) *reinterpret_cast<float4*>(sa + a_lds[i]) = ra[i];   // uniform
+            else *reinterpret_cast<float4*>(sa + a_lds[i]) = a_k[i] >= shift ? ra[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < Cfg::X_F4; ++i) {
@@ -204,13 +205,19 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
     store_chunk(0, 0);
     __syncthreads();
     load_chunk(nchunks > 1 ? 1 : 0);
-    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+    // The first chunk is peeled out of the loop: its first products then START the accumulators (MFMA with a literal zero C)
+    // instead of adding to 128 registers that had to be cleared one by one.
+    auto chunk_step = [&](int ch) {
         const int buf = ch & 1;
         mfma_block(buf, 0, QH);
         store_chunk(buf ^ 1, ch + 1);
         load_chunk(ch + 2 < nchunks ? ch + 2 : nchunks - 1);   // the tail re-reads the last chunk (unused)
         mfma_block(buf, QH, QN);
         __syncthreads();
+    };
+    if (nchunks > 1) {
+        chunk_step(0);
+        for (int ch = 1; ch + 1 < nchunks; ++ch) chunk_step(ch);
     }
     mfma_block((nchunks - 1) & 1, 0, QN);
 
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __res
         float u[4][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float g0 = u_ok ? g[3 * c] : 0.f, g1 = u_ok ? g[3 * c + 1] : 0.f, g2 = u_ok ? g[3 * c + 2] : 0.f;
+            const float g0 = g[3 * c], g1 = g[3 * c + 1], g2 = g[3 * c + 2];   // (rows past Cout: row 0's weights, never stored)
             u[0][c] = g0;
             u[1][c] = ((g0 + g2) + g1) * 0.5f;
             u[2][c] = ((g0 + g2) - g1) * 0.5f;
