@@ -163,6 +163,14 @@ __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __res
         bidx = lo < best ? code : bidx;
         best = fminf(best, lo);
     };
+    // the same with the winner tracked as a small literal (the k-step) inside a half-tile: no index arithmetic per score
+    int loc = 0;
+    auto fold_loc = [&](float a, float e2, float nk, int step) {
+        const float lo = fmaf(-ax, nk, fmaf(-2.f, a, e2));
+        second = __builtin_amdgcn_fmed3f(best, second, lo);
+        loc = lo < best ? step : loc;
+        best = fminf(best, lo);
+    };
     // A tile is searched as two half-tiles of 32 codes, each one accumulator chain of 16 k-steps x three piece products (small
     // terms first; a single chain of v_mfma_f32_32x32x16_bf16 runs at the full rate); the code fragments of step s+1 are
     // requested before the products of step s.  The 16 scores per lane of the PREVIOUS half-tile are folded into the running
@@ -181,6 +189,8 @@ __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __res
         const int pcode = ptile * kSTile + (1 - half) * 32 + 4 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r) cur[r] = 0.f;
+        const float best_in = best;   // (fold_prev) the previous half-tile's winner, if any, becomes a code index after the steps
+        loc = 0;
         bf16x8 af[2][2];   // [parity][piece 1, piece 2]
         float ke[2], kn[2];
         auto load_s = [&](int s_, int par) {
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __res
             cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], x2[s_], cur, 0, 0, 0);
             cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], x1[s_], cur, 0, 0, 0);
             if constexpr (fold_prev) {
-                fold(prev[s_], ke[s_ & 1], kn[s_ & 1], pcode + (s_ & 3) + 8 * (s_ >> 2));
+                fold_loc(prev[s_], ke[s_ & 1], kn[s_ & 1], s_);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {   // one MFMA, then two of the six fold instructions, ...
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -210,6 +220,7 @@ __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __res
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (fold_prev) bidx = best < best_in ? pcode + (loc & 3) + 8 * (loc >> 2) : bidx;
         if (half == 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows this wave copied for the next tile have landed
             __syncthreads();
