@@ -245,6 +245,16 @@ int lbm_conv1d_bf16x6_f32(const float* x, int64_t ldx, const void* tables, const
                           int32_t Cin, int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
                           lbm_stream_t stream);
 
+/* The 3-tap, stride-1, padding-1 layer (the encoder's third convolution, training/model.py:174) with its Winograd-transformed weights
+ * taken from a caller-owned table instead of being rebuilt from w by every workgroup: same arithmetic, same results bit for bit as
+ * lbm_conv1d_pitched_f32 on that shape, ~4 % faster (the per-chunk weight loads become four coalesced 16-byte loads per thread).
+ * lbm_conv1d_wino3_tables_bytes(Cin, Cout): size of the 16-byte aligned device table (0 = unsupported: Cin % 8 != 0 or Cout < 64);
+ * lbm_conv1d_wino3_tables_init fills it from w [Cout, Cin, 3].  x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32. */
+size_t lbm_conv1d_wino3_tables_bytes(int32_t Cin, int32_t Cout);
+int lbm_conv1d_wino3_tables_init(void* tables, const float* w, int32_t Cin, int32_t Cout, lbm_stream_t stream);
+int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tables, const float* bias, float* y, int64_t ldy, int64_t B,
+                         int32_t Cin, int32_t Lin, int32_t Cout, int32_t relu, lbm_stream_t stream);
+
 /* ---- a12 / a13: codebook distance + argmin ----------------------------------------------------------
  * Replaces VectorQuantizerEMA.get_code_indices, training/model.py:152-158 (same math in forward :90-95):
  * d[n,k] = (sum(x_n^2) + sum(e_k^2)) - 2 * (x_n . e_k) in fp32, idx[n] = first k attaining the minimum.

@@ -260,6 +260,28 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
 // V's are formed on the fly from four raw-window reads per input channel, the U's when the weight slab is
 // staged.  fp32 throughout; differs from the direct form by a few ulp of |x||w| (the same order as the
 // difference between two BLAS libraries; vendor conv libraries use this transform for 3-tap fp32 convs).
+// Pre-transformed weights of the Winograd kernel (lbm_conv1d_wino3_tables_init): U in the order the staging threads consume it,
+// [chunk of 8 input channels][tile of 128 output channels][transform i][thread tid = 2 co + quad][4 floats] -- one chunk's slab is four
+// fully coalesced 16-byte loads per thread instead of three 48-byte-strided ones plus the transform (stamps, round 2: issuing
+// those loads cost a wave ~990 of a chunk's ~5 700 cycles; the table's cost ~250).  Rows past Cout are zero.
+__global__ __launch_bounds__(256) void wino3_table_kernel(const float* __restrict__ w, float* __restrict__ tab, int Cin, int Cout, int mtiles) {
+    const int tid = threadIdx.x, ch = blockIdx.x, mt = blockIdx.y;
+    const int co = mt * 128 + (tid >> 1), cq = tid & 1;
+    float u[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* g = w + ((int64_t)(co < Cout ? co : 0) * Cin + ch * 8 + 4 * cq + c) * 3;
+        const float g0 = co < Cout ? g[0] : 0.f, g1 = co < Cout ? g[1] : 0.f, g2 = co < Cout ? g[2] : 0.f;
+        u[0][c] = g0;
+        u[1][c] = ((g0 + g2) + g1) * 0.5f;
+        u[2][c] = ((g0 + g2) - g1) * 0.5f;
+        u[3][c] = g2;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        reinterpret_cast<float4*>(tab)[(((int64_t)ch * mtiles + mt) * 4 + i) * 256 + tid] = make_float4(u[i][0], u[i][1], u[i][2], u[i][3]);
+}
+
 struct WinoCfg {
     static constexpr int BM = 128, CK = 8;
     static constexpr int LDU = CK + 4;                   // padded U row (conflict-free ds_read_b128)
@@ -270,7 +292,8 @@ struct WinoCfg {
     static constexpr size_t LDS_FLOATS = 2 * (size_t)(USZ + XSZ);
 };
 
-template <int VEC>
+// UTAB: w is the pre-transformed table above instead of the [Cout, Cin, 3] weights (same U values, so the same results bit for bit)
+template <int VEC, bool UTAB>
 __global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               int Cin, int Lin, int ldx, int Cout, int Lout, int ldy,
@@ -305,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __res
     const int u_co = threadIdx.x >> 1, u_cq = threadIdx.x & 1;
     const bool u_ok = m0 + u_co < Cout;
     const int u_off = ((u_ok ? m0 + u_co : 0) * Cin + 4 * u_cq) * 3;
-    float4 rw[3];
+    float4 rw[UTAB ? 4 : 3];
     float4 rx[Cfg::X_F4];
     int x_o[Cfg::X_F4][VEC == 4 ? 1 : 4], x_lds[Cfg::X_F4];
     bool x_ok[Cfg::X_F4][4];
@@ -327,10 +350,16 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __res
     }
 
     auto load_chunk = [&](int ch) {
-        const float* wc = w + ch * CK * 3;
         const float* xc = xb + (int64_t)ch * CK * ldx;
+        if constexpr (UTAB) {
+            const float4* ut = reinterpret_cast<const float4*>(w) + ((int64_t)(ch * mtiles + mt) * 4) * kThreads + threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const float4*>(wc + u_off + 4 * i);
+            for (int i = 0; i < 4; ++i) rw[i] = ut[i * kThreads];
+        } else {
+            const float* wc = w + ch * CK * 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rw[i] = *reinterpret_cast<const float4*>(wc + u_off + 4 * i);
+        }
 #pragma unroll
         for (int i = 0; i < Cfg::X_F4; ++i) {
             if constexpr (VEC == 4) rx[i] = load_quad<4>(xc, x_o[i][0], 0, 0, 0);
@@ -340,22 +369,30 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __res
     auto store_chunk = [&](int buf) {
         float* su = s_u0 + buf * Cfg::USZ + u_co * LDU + 4 * u_cq;
         float* sx = s_x0 + buf * Cfg::XSZ;
+        if constexpr (UTAB) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(rw[i].x), "+v"(rw[i].y), "+v"(rw[i].z), "+v"(rw[i].w));
-        const float g[12] = {rw[0].x, rw[0].y, rw[0].z, rw[0].w, rw[1].x, rw[1].y, rw[1].z, rw[1].w,
-                             rw[2].x, rw[2].y, rw[2].z, rw[2].w};   // [ci 0..3][tap 0..2]
-        float u[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float g0 = g[3 * c], g1 = g[3 * c + 1], g2 = g[3 * c + 2];   // (rows past Cout: row 0's weights, never stored)
-            u[0][c] = g0;
-            u[1][c] = ((g0 + g2) + g1) * 0.5f;
-            u[2][c] = ((g0 + g2) - g1) * 0.5f;
-            u[3][c] = g2;
+            for (int i = 0; i < 4; ++i) {
+                asm volatile("" : "+v"(rw[i].x), "+v"(rw[i].y), "+v"(rw[i].z), "+v"(rw[i].w));
+                *reinterpret_cast<float4*>(su + i * (BM * LDU)) = rw[i];
+            }
+        } else {
+    #pragma unroll
+            for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(rw[i].x), "+v"(rw[i].y), "+v"(rw[i].z), "+v"(rw[i].w));
+            const float g[12] = {rw[0].x, rw[0].y, rw[0].z, rw[0].w, rw[1].x, rw[1].y, rw[1].z, rw[1].w,
+                                 rw[2].x, rw[2].y, rw[2].z, rw[2].w};   // [ci 0..3][tap 0..2]
+            float u[4][4];
+    #pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float g0 = g[3 * c], g1 = g[3 * c + 1], g2 = g[3 * c + 2];   // (rows past Cout: row 0's weights, never stored)
+                u[0][c] = g0;
+                u[1][c] = ((g0 + g2) + g1) * 0.5f;
+                u[2][c] = ((g0 + g2) - g1) * 0.5f;
+                u[3][c] = g2;
+            }
+    #pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(su + i * (BM * LDU)) = make_float4(u[i][0], u[i][1], u[i][2], u[i][3]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(su + i * (BM * LDU)) = make_float4(u[i][0], u[i][1], u[i][2], u[i][3]);
 #pragma unroll
         for (int i = 0; i < Cfg::X_F4; ++i) {
             asm volatile("" : "+v"(rx[i].x), "+v"(rx[i].y), "+v"(rx[i].z), "+v"(rx[i].w));
@@ -567,14 +604,14 @@ int launch_tile(const float* x, const float* w, const float* bias, float* y, int
 }
 
 int launch_wino3(const float* x, const float* w, const float* bias, float* y, int64_t B, int Cin, int Lin, int64_t ldx, int Cout,
-                 int Lout, int64_t ldy, int relu, hipStream_t st) {
+                 int Lout, int64_t ldy, int relu, hipStream_t st, bool utab = false) {
     const int ptiles = (Lout + BN - 1) / BN;
     const int mtiles = (Cout + WinoCfg::BM - 1) / WinoCfg::BM;
     const int64_t blocks = B * ptiles * mtiles;
     if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_conv1d_f32: grid too large");
     const size_t lds = WinoCfg::LDS_FLOATS * sizeof(float);
     const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && ldx >= 4 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-    auto k = vec ? conv_wino3_kernel<4> : conv_wino3_kernel<1>;
+    auto k = utab ? (vec ? conv_wino3_kernel<4, true> : conv_wino3_kernel<1, true>) : (vec ? conv_wino3_kernel<4, false> : conv_wino3_kernel<1, false>);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_conv1d_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -626,4 +663,36 @@ extern "C" int lbm_conv1d_f32(const float* x, const float* w, const float* bias,
                               lbm_stream_t stream) {
     const int64_t Lout = (ksize >= 1 && stride >= 1) ? ((int64_t)Lin + 2 * pad - ksize) / stride + 1 : 0;
     return lbm_conv1d_pitched_f32(x, Lin, w, bias, y, Lout, B, Cin, Lin, Cout, ksize, stride, pad, relu, stream);
+}
+
+// ---- Winograd layer with pre-transformed weights (caller-owned table)
+extern "C" size_t lbm_conv1d_wino3_tables_bytes(int32_t Cin, int32_t Cout) {
+    if (Cin < 8 || Cin % 8 != 0 || Cout < 64) return 0;
+    return (size_t)(Cin / 8) * ((Cout + WinoCfg::BM - 1) / WinoCfg::BM) * 4 * kThreads * sizeof(float4);
+}
+
+extern "C" int lbm_conv1d_wino3_tables_init(void* tables, const float* w, int32_t Cin, int32_t Cout, lbm_stream_t stream) {
+    LBM_REQUIRE(tables && w, LBM_EINVAL, "lbm_conv1d_wino3_tables_init: NULL pointer");
+    LBM_REQUIRE(lbm_conv1d_wino3_tables_bytes(Cin, Cout) != 0, LBM_EUNSUPPORTED,
+                "lbm_conv1d_wino3_tables_init: Cin=%d must be a multiple of 8, Cout=%d at least 64", Cin, Cout);
+    LBM_REQUIRE(((uintptr_t)tables & 15) == 0, LBM_EINVAL, "lbm_conv1d_wino3_tables_init: tables must be 16-byte aligned");
+    const int mtiles = (Cout + WinoCfg::BM - 1) / WinoCfg::BM;
+    hipLaunchKernelGGL(wino3_table_kernel, dim3(Cin / 8, mtiles), dim3(256), 0, lbm::as_stream(stream), w, static_cast<float*>(tables), Cin,
+                       Cout, mtiles);
+    return lbm::check_launch("lbm_conv1d_wino3_tables_init");
+}
+
+extern "C" int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tables, const float* bias, float* y, int64_t ldy, int64_t B,
+                                    int32_t Cin, int32_t Lin, int32_t Cout, int32_t relu, lbm_stream_t stream) {
+    LBM_REQUIRE(B >= 0 && Lin >= 1, LBM_EINVAL, "lbm_conv1d_wino3_f32: bad sizes");
+    LBM_REQUIRE(lbm_conv1d_wino3_tables_bytes(Cin, Cout) != 0, LBM_EUNSUPPORTED,
+                "lbm_conv1d_wino3_f32: Cin=%d must be a multiple of 8, Cout=%d at least 64", Cin, Cout);
+    const int Lout = Lin;   // ksize 3, stride 1, padding 1
+    LBM_REQUIRE(ldx >= Lin && ldy >= Lout, LBM_EINVAL, "lbm_conv1d_wino3_f32: row pitch smaller than the row");
+    LBM_REQUIRE((int64_t)Cin * ldx <= 0x7fffffffLL && (int64_t)Cout * ldy <= 0x7fffffffLL, LBM_EUNSUPPORTED,
+                "lbm_conv1d_wino3_f32: one epoch exceeds 2^31 elements");
+    if (B == 0) return LBM_OK;
+    LBM_REQUIRE(x && tables && y, LBM_EINVAL, "lbm_conv1d_wino3_f32: NULL pointer");
+    LBM_REQUIRE(((uintptr_t)tables & 15) == 0, LBM_EINVAL, "lbm_conv1d_wino3_f32: tables must be 16-byte aligned");
+    return launch_wino3(x, static_cast<const float*>(tables), bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, relu, lbm::as_stream(stream), true);
 }

@@ -105,6 +105,12 @@ class EpochPipeline:
                 from .quantizer import conv_split_tables
                 for i in (4,) if cfg.fold_projection else (4, 6):
                     self.conv_tab[i] = conv_split_tables(self.enc[f"encoder.{i}.weight"])
+            # the third layer's Winograd-transformed weights, built once (same results as transforming them in the kernel)
+            self.wino_tab = None
+            w3 = self.enc["encoder.4.weight"]
+            if 4 not in self.conv_tab and w3.shape[2] == 3 and self.lib.lbm_conv1d_wino3_tables_bytes(w3.shape[1], w3.shape[0]):
+                from .quantizer import conv_wino3_tables
+                self.wino_tab = conv_wino3_tables(w3)
             T = cfg.n_times
             self.L1 = (T + 2 - 4) // 2 + 1
             self.L2 = (self.L1 + 2 - 4) // 2 + 1
@@ -224,7 +230,10 @@ class EpochPipeline:
 
             def conv(xi, ldx, yo, ldy, i, cin, lin, cout, ks, s_, pd, relu):
                 tab = self.conv_tab.get(i)
-                if tab is not None:
+                if i == 4 and tab is None and self.wino_tab is not None and (ks, s_, pd) == (3, 1, 1):
+                    _lib.check(lib.lbm_conv1d_wino3_f32(p(xi), ldx, p(self.wino_tab), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin,
+                                                        cout, relu, st), "conv(wino3)")
+                elif tab is not None:
                     _lib.check(lib.lbm_conv1d_bf16x6_f32(p(xi), ldx, p(tab), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin, cout,
                                                          ks, s_, pd, relu, st), "conv(bf16x6)")
                 else:

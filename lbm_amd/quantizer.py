@@ -202,12 +202,29 @@ def conv_split_tables(weight: torch.Tensor) -> torch.Tensor:
     return tab
 
 
+def conv_wino3_tables(weight: torch.Tensor) -> torch.Tensor:
+    """Device table of the Winograd-transformed weights of a 3-tap, stride-1, padding-1 layer [Cout, Cin, 3]
+    (``lbm_conv1d_wino3_tables_init``), the form ``conv1d(..., wino_tables=...)`` / ``lbm_conv1d_wino3_f32`` consume."""
+    w = _lib.dev_f32(weight)
+    Cout, Cin, ks = w.shape
+    lib = _lib.load()
+    nbytes = lib.lbm_conv1d_wino3_tables_bytes(Cin, Cout) if ks == 3 else 0
+    if nbytes == 0:
+        raise NotImplementedError(f"conv_wino3_tables: unsupported weight shape {tuple(w.shape)} (3 taps, Cin % 8 == 0, Cout >= 64)")
+    tab = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.lbm_conv1d_wino3_tables_init(_lib.ptr(tab), _lib.ptr(w), Cin, Cout, _lib.stream_ptr()), "lbm_conv1d_wino3_tables_init")
+    return tab
+
+
 def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, stride: int = 1, padding: int = 0,
-           relu: bool = False, pitched_out: bool = False, split_tables: torch.Tensor = None) -> torch.Tensor:
+           relu: bool = False, pitched_out: bool = False, split_tables: torch.Tensor = None,
+           wino_tables: torch.Tensor = None) -> torch.Tensor:
     """nn.Conv1d (+ReLU) forward on fp32 MFMA.  x: [B, Cin, L] (contiguous or a pitched view); weight: [Cout, Cin, k].
     ``pitched_out`` returns a [B, Cout, Lout] view of a row-padded buffer (what the next layer reads fastest).
     ``split_tables`` (from ``conv_split_tables(weight)``) selects the bf16-piece kernel (fp32-grade products on the
-    bf16 matrix cores; results within fp32 rounding of the default kernel)."""
+    bf16 matrix cores; results within fp32 rounding of the default kernel).  ``wino_tables`` (from
+    ``conv_wino3_tables(weight)``; 3 taps, stride 1, padding 1) takes the Winograd-transformed weights from that table: the
+    default kernel's results bit for bit, a few percent faster."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
         x = _lib.dev_f32(x)
     x = _pitched_rows(x)
@@ -221,6 +238,12 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, str
     y = pitched_empty(B, Cout, Lout, x.device) if pitched_out else torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
     ldx = x.stride(1) if B * Cin > 1 else Lin
     ldy = y.stride(1) if B * Cout > 1 else Lout
+    if wino_tables is not None:
+        if (ks, stride, padding) != (3, 1, 1):
+            raise ValueError("wino_tables is for 3-tap, stride-1, padding-1 layers")
+        _lib.check(_lib.load().lbm_conv1d_wino3_f32(_lib.ptr(x), ldx, _lib.ptr(wino_tables), _lib.ptr(b), _lib.ptr(y), ldy, B, Cin, Lin,
+                                                    Cout, int(relu), _lib.stream_ptr()), "lbm_conv1d_wino3_f32")
+        return y
     if split_tables is not None:
         _lib.check(_lib.load().lbm_conv1d_bf16x6_f32(_lib.ptr(x), ldx, _lib.ptr(split_tables), _lib.ptr(b), _lib.ptr(y), ldy, B, Cin,
                                                      Lin, Cout, ks, stride, padding, int(relu), _lib.stream_ptr()),

@@ -319,6 +319,32 @@ def test_conv1d_matches_torch_cpu(B, Cin, L, Cout, k, s, p):
         assert float((y.double() - want).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,L,Cout", [(3, 128, 375, 256), (2, 64, 2500, 256), (1, 8, 5, 64), (2, 24, 130, 200), (1, 16, 1, 96)])
+def test_conv1d_wino3_table_is_bitwise_the_default_kernel(B, Cin, L, Cout):
+    """lbm_conv1d_wino3_f32 (Winograd-transformed weights from a caller-owned table) = lbm_conv1d_pitched_f32 on the same shape, bit
+    for bit, for dense and pitched rows, with and without ReLU / bias."""
+    from lbm_amd.quantizer import pitched_empty
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    x = torch.randn(B, Cin, L, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, generator=g) / math.sqrt(Cin * 3)).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    tab = lbm_amd.conv_wino3_tables(w)
+    for relu in (False, True):
+        for bias in (b, None):
+            want = lbm_amd.conv1d(x, w, bias, 1, 1, relu)
+            assert torch.equal(lbm_amd.conv1d(x, w, bias, 1, 1, relu, wino_tables=tab), want)
+    xp = pitched_empty(B, Cin, L, DEV)
+    xp.copy_(x)
+    got = lbm_amd.conv1d(xp, w, b, 1, 1, True, pitched_out=True, wino_tables=tab)
+    assert got.stride(1) % 4 == 0 and torch.equal(got, lbm_amd.conv1d(x, w, b, 1, 1, True))
+    ref = torch.nn.functional.conv1d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1).relu()
+    assert float((got.double().cpu() - ref).abs().max()) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        lbm_amd.conv_wino3_tables(torch.zeros(64, 12, 3))
+    with pytest.raises(ValueError):
+        lbm_amd.conv1d(x, w, b, 2, 1, True, wino_tables=tab)
+
+
 @pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 30, 1500, 64, 4, 2, 1), (2, 64, 750, 128, 4, 2, 1), (2, 128, 375, 256, 3, 1, 1),
                                                 (2, 256, 375, 256, 1, 1, 0), (2, 12, 130, 40, 3, 1, 1), (1, 20, 9, 7, 1, 1, 0)])
 def test_conv1d_pitched_rows_bitwise_equal_dense(B, Cin, L, Cout, k, s, p):

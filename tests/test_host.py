@@ -157,3 +157,15 @@ def test_vq_screen_workspace_and_arguments():
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 250, 512, None) == -2
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 7, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
+
+
+def test_conv_wino3_table_sizes_and_arguments():
+    lib = _lib.load()
+    assert lib.lbm_conv1d_wino3_tables_bytes(128, 256) == 16 * 2 * 4 * 256 * 16
+    assert lib.lbm_conv1d_wino3_tables_bytes(64, 64) == 8 * 1 * 4 * 256 * 16
+    assert lib.lbm_conv1d_wino3_tables_bytes(30, 256) == 0 and lib.lbm_conv1d_wino3_tables_bytes(128, 32) == 0
+    assert lib.lbm_conv1d_wino3_tables_init(None, None, 128, 256, None) == -1
+    assert lib.lbm_conv1d_wino3_f32(None, 376, None, None, None, 376, 0, 128, 375, 256, 1, None) == 0      # B == 0
+    assert lib.lbm_conv1d_wino3_f32(None, 376, None, None, None, 376, 4, 128, 375, 256, 1, None) == -1     # NULL pointers
+    assert lib.lbm_conv1d_wino3_f32(None, 376, None, None, None, 376, 4, 30, 375, 256, 1, None) == -2      # Cin % 8
+    assert lib.lbm_conv1d_wino3_f32(None, 100, None, None, None, 376, 4, 128, 375, 256, 1, None) == -1     # pitch < row

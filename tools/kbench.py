@@ -110,6 +110,9 @@ def main():
         xin = rnd(E, cin, ldx)
         yo = torch.empty(E, cout, ldy, device=dev)
         fn = lambda: lib.lbm_conv1d_pitched_f32(p(xin), ldx, p(wt), p(bs), p(yo), ldy, E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
+        if s == "conv3" and not args.split and not args.cin and not args.dense:   # as the pipeline runs it: transformed weights from a table
+            wtab = lbm_amd.conv_wino3_tables(wt)
+            fn = lambda: lib.lbm_conv1d_wino3_f32(p(xin), ldx, p(wtab), p(bs), p(yo), ldy, E, cin, lin, cout, relu, st)  # noqa: E731
         if args.split:
             ctab = lbm_amd.conv_split_tables(wt)
             fn = lambda: lib.lbm_conv1d_bf16x6_f32(p(xin), ldx, p(ctab), p(bs), p(yo), ldy, E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
