@@ -247,7 +247,8 @@ int lbm_conv1d_bf16x6_f32(const float* x, int64_t ldx, const void* tables, const
 
 /* The 3-tap, stride-1, padding-1 layer (the encoder's third convolution, training/model.py:174) with its Winograd-transformed weights
  * taken from a caller-owned table instead of being rebuilt from w by every workgroup: same arithmetic, same results bit for bit as
- * lbm_conv1d_pitched_f32 on that shape, ~4 % faster (the per-chunk weight loads become four coalesced 16-byte loads per thread).
+ * lbm_conv1d_pitched_f32 on that shape (the per-chunk weight loads become four coalesced 16-byte loads per thread: 3-4 % faster on
+ * dense random inputs, within noise on the encoder's own post-ReLU activations).
  * lbm_conv1d_wino3_tables_bytes(Cin, Cout): size of the 16-byte aligned device table (0 = unsupported: Cin % 8 != 0 or Cout < 64);
  * lbm_conv1d_wino3_tables_init fills it from w [Cout, Cin, 3].  x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32. */
 size_t lbm_conv1d_wino3_tables_bytes(int32_t Cin, int32_t Cout);
