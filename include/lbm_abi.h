@@ -208,6 +208,15 @@ int lbm_welch_scaled_f32(const float* x, const float* row_scale, float* psd, flo
                          float fs, int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
                          int32_t bin_hi, int32_t average_mode, lbm_stream_t stream);
 
+/* lbm_welch_f32 (mean over segments) with the peak-to-peak reject test of the epoch stage riding along: keep[e] = 0 where any
+ * channel of epoch e has max - min > ptp_thresh (reject=dict(eeg=150e-6), multi-train/withpsd.py:213-219), 1 otherwise -- the
+ * features-only flow (PSD + band powers of unfiltered epochs, BASELINE config 2) then reads every epoch once instead of twice.
+ * x: [E, C, T]; psd: [E, C, F]; keep: [E].  Where the launch is not the team kernel the test runs as its own pass; results are
+ * those of lbm_epoch_post_f32's mask and lbm_welch_f32 either way. */
+int lbm_welch_keep_f32(const float* x, float* psd, uint8_t* keep, int64_t E, int32_t C, int32_t T, float fs, int32_t nfft,
+                       int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo, int32_t bin_hi, float ptp_thresh,
+                       lbm_stream_t stream);
+
 /* ---- a8: theta/alpha/beta band powers and ratios ----------------------------------------------------
  * Replaces preprocessing_unsupervised.py:45-61 (also :102-110, failed/label.py:13-23):
  * log = 10*log10(psd) (skipped when already_db), theta = mean over channels x bins with 4<=f<8,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "lbm_welch_tables_init": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p]),
     "lbm_welch_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p]),
     "lbm_welch_scaled_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _i32, _i32, _i32, _p, _i32, _i32, _i32, _p]),
+    "lbm_welch_keep_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _p, _i32, _i32, _f32, _p]),
     "lbm_bandpower_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_pitched_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),

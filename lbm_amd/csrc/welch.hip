@@ -423,16 +423,19 @@ constexpr int kTeamSteps = 16;  // k-steps per wave held in registers (QS / TS r
 
 __host__ __device__ inline int team_rows_pad(int rows_floats) { return (rows_floats + 255) & ~255; }   // whole 1 KiB DMA units
 
-template <int TS, int NTILES>
+// KEEP (lbm_welch_keep_f32): the peak-to-peak reject test of the epoch post-processing (keep[row / C] = 0 where max - min > thresh) rides
+// along -- the rows are in LDS anyway -- so the features-only branch needs no separate pass over the epochs.
+template <int TS, int NTILES, bool KEEP = false>
 __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 2 && NTILES == 1) ? 3 : 2, (TS == 2 && NTILES == 1) ? 3 : 2))) void welch_team_kernel(
     const float* __restrict__ x, const float* __restrict__ row_scale, float* __restrict__ psd, int64_t rows, int T, double fs, FoldGeom g,
-    const void* __restrict__ tables, int bin_lo, int F, int64_t ngroups) {
+    const void* __restrict__ tables, int bin_lo, int F, int64_t ngroups, uint8_t* __restrict__ keep = nullptr, int C = 1, float ptp_thresh = 0.f) {
     extern __shared__ __align__(16) float smem[];
     float* s_rows = smem;                                            // [RW][T], padded to whole DMA units
     float4* s_part = reinterpret_cast<float4*>(s_rows + team_rows_pad(g.rows_floats));   // [NTILES][TS-1][4][64] float4
     float* s_P = reinterpret_cast<float*>(s_part + NTILES * (TS - 1) * 4 * 64);          // [NTILES*16][kLdp]
     float* s_mean = s_P + NTILES * 16 * kLdp;                        // [NTILES*16]
     float* s_win = s_mean + NTILES * 16;                             // [H+1]
+    float* s_mm = s_win + ((g.H + 1 + 3) & ~3);                       // KEEP: [RW][TS][2] min / max partials of the group's rows
     const int lane = threadIdx.x & 63, tw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // tw in an SGPR: its branches are scalar
     const int j = lane & 15, kq = lane >> 4;
 
@@ -489,6 +492,27 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
         const int nsegs = nrows * g.nseg;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // B: this group's rows have landed (first group: the window too)
+        if constexpr (KEEP) {   // min / max of every row of the group: 16-byte LDS reads, lanes strided over the row, one shuffle tree per row
+            const int q4 = T >> 2;
+            for (int r = 0; r < nrows; ++r) {
+                const float4* rp = reinterpret_cast<const float4*>(s_rows + r * T);
+                float mn = INFINITY, mx = -INFINITY;
+                for (int q = threadIdx.x; q < q4; q += 64 * TS) {
+                    const float4 v = rp[q];
+                    mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
+                    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    mn = fminf(mn, __shfl_xor(mn, d, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+                }
+                if (lane == 0) {
+                    s_mm[(r * TS + tw) * 2] = mn;
+                    s_mm[(r * TS + tw) * 2 + 1] = mx;
+                }
+            }
+        }
         // ---- per-segment means (scipy detrend='constant') -- only where the mean can reach the requested bins
         if (!mean_free) {   // uniform
             for (int sg0 = 16 * tw; sg0 < NTILES * 16; sg0 += 16 * TS) {
@@ -581,6 +605,17 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
             for (int a = 0; a < 4; ++a) accs[tile][a] = acc[a];
         }
         __syncthreads();   // C: every wave of the team is done reading the rows (and, from the previous group, P)
+        if constexpr (KEEP) {
+            if ((int)threadIdx.x < nrows) {   // one thread per row combines the waves' partials (rewritten only after the next barrier B)
+                float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < TS; ++w) {
+                    mn = fminf(mn, s_mm[(threadIdx.x * TS + w) * 2]);
+                    mx = fmaxf(mx, s_mm[(threadIdx.x * TS + w) * 2 + 1]);
+                }
+                if (mx - mn > ptp_thresh) keep[(row0 + threadIdx.x) / C] = 0;
+            }
+        }
         // ---- the NEXT group's rows are requested as soon as the row buffer is free; they land under the rest of this
         // iteration.  An LDS-DMA piece costs its wave ~200 cycles of issue here (stamps), so the pieces are spread: over both
         // waves of a team of two; in a team of four over the waves that own no tile, while the owners sum (after barrier D).
@@ -793,9 +828,11 @@ extern "C" int lbm_welch_tables_init(void* tables, int32_t nfft, int32_t nperseg
 }
 
 namespace {
+// keep != nullptr: the caller wants the reject test fused; *keep_done says whether this launch did it (team path only)
 int welch_impl(const float* x, const float* row_scale, float* psd, float* seg_or_null, int64_t rows, int32_t T, float fs,
                int32_t nfft, int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo,
-               int32_t bin_hi, int32_t average_mode, lbm_stream_t stream) {
+               int32_t bin_hi, int32_t average_mode, lbm_stream_t stream, uint8_t* keep = nullptr, int C = 1, float ptp_thresh = 0.f,
+               bool* keep_done = nullptr) {
     LBM_REQUIRE(rows >= 0, LBM_EINVAL, "lbm_welch_f32: negative rows");
     LBM_REQUIRE(nperseg >= 1 && nperseg <= nfft, LBM_EINVAL, "lbm_welch_f32: need 1 <= nperseg <= nfft");
     LBM_REQUIRE(nfft <= T, LBM_EINVAL, "lbm_welch_f32: n_fft (%d) is larger than the number of samples (%d)", nfft, T);
@@ -820,7 +857,7 @@ int welch_impl(const float* x, const float* row_scale, float* psd, float* seg_or
         if (((T & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && g.TILES <= 2) {
             const int ts = g.rows_floats <= 6000 ? 2 : 4;
             const size_t lds_t = ((size_t)team_rows_pad(g.rows_floats) + (size_t)g.TILES * (ts - 1) * 1024 +
-                                  (size_t)g.TILES * 16 * (kLdp + 1) + ((g.H + 1 + 3) & ~3)) * sizeof(float);
+                                  (size_t)g.TILES * 16 * (kLdp + 1) + ((g.H + 1 + 3) & ~3) + (keep ? (size_t)g.RW * ts * 2 : 0)) * sizeof(float);
             // every step of a wave's straight line must stay inside its segment: n <= H for the last wave's last step
             const bool in_seg = 4 * (((ts - 1) * g.QS) / ts + kTeamSteps - 1) + 3 <= g.H;
             if ((g.QS + ts - 1) / ts <= kTeamSteps && g.QS >= 2 * ts && in_seg && lds_t <= 80 * 1024) {
@@ -832,11 +869,16 @@ int welch_impl(const float* x, const float* row_scale, float* psd, float* seg_or
                 if (blocks > ngroups) blocks = ngroups;
                 auto k = ts == 2 ? (g.TILES == 1 ? welch_team_kernel<2, 1> : welch_team_kernel<2, 2>)
                                  : (g.TILES == 1 ? welch_team_kernel<4, 1> : welch_team_kernel<4, 2>);
+                if (keep != nullptr) {
+                    k = ts == 2 ? (g.TILES == 1 ? welch_team_kernel<2, 1, true> : welch_team_kernel<2, 2, true>)
+                                : (g.TILES == 1 ? welch_team_kernel<4, 1, true> : welch_team_kernel<4, 2, true>);
+                    if (keep_done) *keep_done = true;
+                }
                 if (lds_t > 48 * 1024 &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t) != hipSuccess)
                     return lbm::fail(LBM_ELAUNCH, "lbm_welch_f32(team): cannot reserve %zu bytes of LDS", lds_t);
                 hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(64 * ts), lds_t, lbm::as_stream(stream), x, row_scale, psd, rows, T,
-                                   (double)fs, g, tables, bin_lo, F, ngroups);
+                                   (double)fs, g, tables, bin_lo, F, ngroups, keep, C, ptp_thresh);
                 return lbm::check_launch("lbm_welch_f32(team)");
             }
         }
@@ -877,6 +919,26 @@ extern "C" int lbm_welch_scaled_f32(const float* x, const float* row_scale, floa
                                     int32_t bin_hi, int32_t average_mode, lbm_stream_t stream) {
     LBM_REQUIRE(rows == 0 || row_scale != nullptr, LBM_EINVAL, "lbm_welch_scaled_f32: NULL row_scale");
     return welch_impl(x, row_scale, psd, seg_or_null, rows, T, fs, nfft, nperseg, noverlap, tables, bin_lo, bin_hi, average_mode, stream);
+}
+
+// post.hip
+extern "C" int lbm_epoch_post_f32(const float* x, float* y_base, float* y_std, uint8_t* keep, int64_t E, int32_t C, int32_t T,
+                                  int32_t n_baseline, float ptp_thresh, int32_t standardize_mode, float eps, lbm_stream_t stream);
+
+extern "C" int lbm_welch_keep_f32(const float* x, float* psd, uint8_t* keep, int64_t E, int32_t C, int32_t T, float fs, int32_t nfft,
+                                  int32_t nperseg, int32_t noverlap, const void* tables, int32_t bin_lo, int32_t bin_hi, float ptp_thresh,
+                                  lbm_stream_t stream) {
+    LBM_REQUIRE(E >= 0 && C >= 1, LBM_EINVAL, "lbm_welch_keep_f32: bad sizes");
+    if (E == 0) return LBM_OK;
+    LBM_REQUIRE(keep != nullptr, LBM_EINVAL, "lbm_welch_keep_f32: NULL keep");
+    hipError_t e = hipMemsetAsync(keep, 1, (size_t)E, lbm::as_stream(stream));
+    if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_welch_keep_f32: memset keep: %s", hipGetErrorString(e));
+    bool fused = false;
+    const int rc = welch_impl(x, nullptr, psd, nullptr, E * C, T, fs, nfft, nperseg, noverlap, tables, bin_lo, bin_hi, LBM_AVG_MEAN, stream,
+                              keep, C, ptp_thresh, &fused);
+    if (rc != LBM_OK || fused) return rc;
+    // the launch above was not the team kernel: the reject test as its own pass (the post kernel in its mask-only form)
+    return lbm_epoch_post_f32(x, nullptr, nullptr, keep, E, C, T, 0, ptp_thresh, LBM_STD_NONE, 0.f, stream);
 }
 
 extern "C" int lbm_bandpower_f32(const float* psd, const float* freqs, float* out, int64_t E, int32_t C, int32_t F,

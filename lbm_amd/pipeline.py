@@ -214,6 +214,14 @@ class EpochPipeline:
                 cur = B["clean"]
                 t0 = mark("affine", t0)
             base = B["clean"] if c.emit_cleaned else cur      # the PSD is the same with or without the baseline offset
+            if not c.emit_cleaned and not c.do_tokenize:
+                # features only: the post stage would write nothing but the keep mask -- the Welch kernel takes the reject test along
+                _lib.check(lib.lbm_welch_keep_f32(p(cur), p(B["psd"]), p(B["keep"]), E, C, T, float(c.sfreq), self.n_fft, self.n_fft,
+                                                  self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, float(c.reject), st), "welch+keep")
+                t0 = mark("welch", t0)
+                _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
+                t0 = mark("bandpower", t0)
+                return {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"]}
             _lib.check(lib.lbm_epoch_post_f32(p(cur), p(base) if c.emit_cleaned else None, p(B["std"]) if c.do_tokenize else None,
                                               p(B["keep"]), E, C, T, c.n_baseline, float(c.reject), std_mode, c.zscore_eps, st), "post")
             t0 = mark("post", t0)

@@ -229,6 +229,30 @@ def test_welch_team_kernel_offsets_and_ragged_groups(rows, T, fs, nfft, fmin):
     assert _psd_err(psd.cpu().numpy(), want) <= 1.0
 
 
+@pytest.mark.parametrize("E,C,T,fs,nfft", [(37, 30, 1500, 500.0, 500), (5, 4, 10000, 1000.0, 1000), (9, 3, 1502, 500.0, 500), (4, 2, 600, 100.0, 100)])
+def test_welch_keep_fused_reject_mask(E, C, T, fs, nfft):
+    """lbm_welch_keep_f32: the PSD of lbm_welch_f32 bit for bit and the keep mask of lbm_epoch_post_f32 (oracle: ptp_keep_mask), on
+    the team kernel's shapes (fused) and on one it does not take (separate pass)."""
+    from lbm_amd.psd import welch_bins, welch_tables
+    x = synth_epochs(E, C, T, sfreq=fs, seed=E) * 2.0
+    x[1, C - 1, T // 3] += 2e-4        # one sample out of range in two epochs
+    x[E - 1, 0, T - 1] -= 3e-4
+    xd = x.to(DEV)
+    _, lo, hi = welch_bins(fs, nfft, 4.0, 30.0)
+    tab = welch_tables(DEV, nfft, nfft, "hann", lo, hi)
+    lib, p_, st = lbm_amd._lib.load(), lbm_amd._lib.ptr, lbm_amd._lib.stream_ptr()
+    psd = torch.empty(E, C, hi - lo + 1, device=DEV)
+    ref = torch.empty_like(psd)
+    keep = torch.full((E,), 7, dtype=torch.uint8, device=DEV)
+    assert lib.lbm_welch_f32(p_(xd), p_(ref), None, E * C, T, fs, nfft, nfft, nfft // 2, p_(tab), lo, hi, 0, st) == 0
+    for _ in range(2):
+        assert lib.lbm_welch_keep_f32(p_(xd), p_(psd), p_(keep), E, C, T, fs, nfft, nfft, nfft // 2, p_(tab), lo, hi, 150e-6, st) == 0
+        assert torch.equal(psd, ref)
+        want = orc.ptp_keep_mask(x.numpy().astype(np.float64), 150e-6)
+        assert np.array_equal(keep.cpu().numpy().astype(bool), want)
+        assert int((~want).sum()) == 2
+
+
 def test_welch_average_modes_and_errors():
     x = synth_epochs(2, 3, 1500, seed=9)
     xd = x.to(DEV)
