@@ -173,15 +173,16 @@ def extra_configs(dev, taps, A, b, weights):
     C5, T5, fs5, K5, E5, ch5 = 64, 10000, 1000.0, 8192, 16384, 1024
     taps5 = lbm_amd.create_filter(fs5, 4.0, 30.0)
     A5, b5 = lbm_amd.ica_projection(**synth_ica(C5))
-    cfg5 = lbm_amd.PipelineConfig(sfreq=fs5, n_channels=C5, n_times=T5, n_baseline=501, emit_cleaned=False, vq_method="screen")
+    cfg5 = lbm_amd.PipelineConfig(sfreq=fs5, n_channels=C5, n_times=T5, n_baseline=501, emit_cleaned=False, vq_method="screen",
+                                  fold_projection=True)     # as the timed config: last layer folded into the codebook, screened search
     enc5, cb5 = synth_encoder(C5), synth_codebook(K5, 256)
     p5 = lbm_amd.EpochPipeline(cfg5, taps5, A5, b5, enc5, cb5, device=dev)
     x5 = synth_epochs(ch5, C5, T5, sfreq=fs5, seed=5, device=dev, chunk=128)
     # the screened quantizer against the fp32 search on the first 256 epochs (640 000 rows x 8192 codes)
     tok5 = p5.run(x5[:256])["tokens"].clone()
     ref5 = int(p5._buf["vq_ws"][:4].view(torch.int32).item())
-    q5 = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(sfreq=fs5, n_channels=C5, n_times=T5, n_baseline=501, emit_cleaned=False),
-                               taps5, A5, b5, enc5, cb5, device=dev)
+    q5 = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(sfreq=fs5, n_channels=C5, n_times=T5, n_baseline=501, emit_cleaned=False,
+                                                      fold_projection=True), taps5, A5, b5, enc5, cb5, device=dev)
     check5 = {"rows": int(tok5.numel()), "tokens_equal_fp32_search": bool(torch.equal(tok5, q5.run(x5[:256])["tokens"])),
               "fraction_searched_in_fp32": round(ref5 / tok5.numel(), 5)}
     del q5, tok5
@@ -193,7 +194,7 @@ def extra_configs(dev, taps, A, b, weights):
         acc.setdefault(name, []).append(s_.elapsed_time(e_))
     p5.stage_events = None
     m5 = stage_model(ch5, C5, T5, len(taps5), K5, 256, p5.S, p5.L1, p5.F, 3 * 4096, vq_method="screen")
-    out["config5"] = {"workload": "16 384 synthetic 64ch x 1 kHz x 10 s epochs, K=8192 codebook, full pipeline, chunks of 1024 "
+    out["config5"] = {"workload": "16 384 synthetic 64ch x 1 kHz x 10 s epochs, K=8192 codebook, full pipeline (folded projection, screened search), chunks of 1024 "
                                   "(one resident 1024-epoch buffer re-walked)",
                       "epochs_per_s": round(E5 / (ms5 * 1e-3), 1), "ms": round(ms5, 2), "stages": stage_report(acc, m5),
                       "screen_check": check5}
