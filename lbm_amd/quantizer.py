@@ -378,34 +378,52 @@ class VQVAE(nn.Module):
             self._fold_key = key
         return self._fold
 
+    def _screen_tables(self, folded: bool):
+        """bf16 piece table of the (folded) codebook for the screened search, rebuilt when the codebook changes."""
+        w = self.vq_layer.embedding.weight
+        key = (folded, w.data_ptr(), w._version, str(w.device), self.vq_layer._cb_epoch,
+               getattr(self, "_fold_key", None) if folded else None)
+        if getattr(self, "_screen_key", None) != key:
+            self._screen_tab = vq_split_tables(self._folded_codebook()[0] if folded else w.detach())
+            self._screen_key = key
+        return self._screen_tab
+
     @torch.no_grad()
-    def encode(self, x, hist=None, fold_projection: bool = False):
+    def encode(self, x, hist=None, fold_projection: bool = False, screened: bool = False):
         """Input x[B, C, L] -> code indices int64 [B, L//4] (training/model.py:206-214), all on HIP kernels;
         the encoder output is consumed channel-major, so the permute(0,2,1).contiguous() copy disappears.
         ``fold_projection=True``: the last 1x1 convolution is folded into the codebook (see ``fold_projection``): its GEMM and
-        the z tensor disappear; indices equal the default's except at documented fp32 near-ties."""
+        the z tensor disappear; indices equal the default's except at documented fp32 near-ties.
+        ``screened=True``: the same indices as without it, bit for bit, from the screened search (``lbm_vq_argmin_screened_f32``:
+        2.4x faster at the shipped sizes)."""
         if fold_projection:
             h = x
             for i, (st, pd) in zip((0, 2, 4), ((2, 1), (2, 1), (1, 1))):
                 h = conv1d(h, self.encoder[i].weight, self.encoder[i].bias, st, pd, True, pitched_out=True)
             cbf, eef = self._folded_codebook()
-            idx = vq_argmin(h, cbf, eef, channel_major=True, no_xnorm=True, hist=hist)
+            tab = self._screen_tables(True) if screened else None
+            idx = vq_argmin(h, cbf, eef, channel_major=True, no_xnorm=True, hist=hist, split_tables=tab, screened=screened)
             return idx.view(x.shape[0], -1)
         z = encoder_forward(x, self.encoder, pitched_out=True)
-        idx = self.vq_layer.get_code_indices_channel_major(z, hist=hist)
+        if screened:
+            vq = self.vq_layer
+            idx = vq_argmin(z.detach(), vq.embedding.weight.detach(), vq._e_sqnorm(), channel_major=True, hist=hist,
+                            split_tables=self._screen_tables(False), screened=True)
+        else:
+            idx = self.vq_layer.get_code_indices_channel_major(z, hist=hist)
         return idx.view(x.shape[0], -1)
 
 
-def encode_data_for_transformer(vq_model, dataloader, device, fold_projection: bool = False):
+def encode_data_for_transformer(vq_model, dataloader, device, fold_projection: bool = False, screened: bool = False):
     """training/model.py:411-427: returns (np.int64 [E, S] indices, np labels).  Batches are encoded
-    back-to-back on the device; indices come back to the host once, after the loop.  ``fold_projection`` (not a reference
-    argument) is handed to ``VQVAE.encode``."""
+    back-to-back on the device; indices come back to the host once, after the loop.  ``fold_projection`` and ``screened`` (not
+    reference arguments) are handed to ``VQVAE.encode``."""
     vq_model.eval()
     all_indices, all_labels = [], []
     with torch.no_grad():
         for data, labels in dataloader:
             data = data.to(device, non_blocking=True)
-            all_indices.append(vq_model.encode(data, fold_projection=True) if fold_projection else vq_model.encode(data))
+            all_indices.append(vq_model.encode(data, fold_projection=fold_projection, screened=screened))
             all_labels.append(labels.numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels))
     all_indices = torch.cat(all_indices, dim=0).cpu().numpy()
     all_labels = np.concatenate(all_labels, axis=0)

@@ -678,6 +678,27 @@ def test_pipeline_screened_quantizer_is_bit_identical(shipped, fold):
     assert torch.equal(out["hist"], 2 * ref["hist"])
 
 
+def test_vqvae_encode_screened_option(shipped, vq_golden):
+    """VQVAE.encode(screened=True) / encode_data_for_transformer(screened=True): the indices of the default search bit for bit, folded
+    or not, also after an in-place EMA update of the codebook (the cached piece tables follow it)."""
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(vq_golden["x_S"]).to(DEV)
+    for fold in (False, True):
+        assert torch.equal(m.encode(x, fold_projection=fold, screened=True), m.encode(x, fold_projection=fold))
+    m.train()
+    with torch.no_grad():
+        m(torch.from_numpy(vq_golden["x_P"]).to(DEV))          # one EMA step rewrites the codebook in place
+    m.eval()
+    for fold in (False, True):
+        assert torch.equal(m.encode(x, fold_projection=fold, screened=True), m.encode(x, fold_projection=fold))
+    loader = [(torch.from_numpy(vq_golden["x_S"]), torch.zeros(2, dtype=torch.int64))]
+    a, _ = lbm_amd.encode_data_for_transformer(m, loader, DEV, screened=True)
+    b, _ = lbm_amd.encode_data_for_transformer(m, loader, DEV)
+    assert np.array_equal(a, b)
+
+
 def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
     m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
