@@ -86,3 +86,18 @@ def test_parent_module_import_does_not_load_the_hip_library():
     import subprocess
     code = "import sys; sys.path.insert(0, %r); import bench; assert 'lbm_amd' not in sys.modules and bench.lbm_amd is None" % ROOT
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_stage_report_executed_flops_and_peaks():
+    """`stages` of the bench line: algorithmic rate against the fp32 matrix peak; where a kernel executes something else (Winograd,
+    the bf16 screen) the executed rate against the peak of the unit it ran on, and for the bf16 unit that is what `frac` reports."""
+    import bench
+    m = bench.stage_model(16384, 30, 1500, 825, 512, 256, 375, 750, 27, vq_method="screen")
+    assert m["vq"]["exec_flops"] == 3 * m["vq"]["flops"] and m["vq"]["peak"] == bench.PEAK_BF16_TFLOPS
+    assert abs(m["conv3"]["exec_flops"] / m["conv3"]["flops"] - 2.0 / 3.0) < 1e-12 and "peak" not in m["conv3"]
+    assert "exec_flops" not in bench.stage_model(16384, 30, 1500, 825, 512, 256, 375, 750, 27)["vq"]
+    rep = bench.stage_report({"vq": [5.0], "conv3": [8.0], "welch": [0.8]}, m)
+    vq, c3, w = rep["vq"], rep["conv3"], rep["welch"]
+    assert abs(vq["executed_tflops"] - 3 * vq["tflops"]) < 0.01 and vq["frac"] == vq["executed_frac"] == round(vq["executed_tflops"] / 2500.0, 4)
+    assert abs(c3["frac"] - c3["tflops"] / bench.PEAK_FP32_TFLOPS) < 1e-4 and abs(c3["executed_frac"] - c3["frac"] * 2 / 3) < 1e-3
+    assert w["bound"] == "hbm" and abs(w["frac"] - w["gbs"] / bench.PEAK_HBM_GBS) < 1e-4 and "executed_frac" not in w
