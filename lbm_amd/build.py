@@ -39,7 +39,7 @@ def up_to_date() -> bool:
 # source is bit-exact).  The build records every kernel's registers / scratch / spills in csrc/_obj/resources.json and refuses
 # a spilling kernel in these files.
 NO_SPILL_FILES = {"vq.hip", "vq_bf16.hip", "vq_screen.hip", "conv_bf16.hip", "welch.hip"}
-NO_SPILL_KERNELS = ("vq_argmin_dma_kernel", "vq_bf16x6_kernel", "vq_screen_kernel", "conv_bf16x6_kernel", "welch_team_kernel")
+NO_SPILL_KERNELS = ("vq_argmin_dma_kernel", "vq_bf16x6_kernel", "vq_screen_kernel", "vq_screen_pipe_kernel", "conv_bf16x6_kernel", "welch_team_kernel")
 
 
 def _resources(remarks: str) -> dict:
