@@ -56,6 +56,31 @@ __global__ __launch_bounds__(256) void vq_screen_consts_kernel(const float* __re
     cee[k] = k < K ? e2 - kBeta * fabsf(e2) : INFINITY;
 }
 
+// LDS-DMA through inline assembly.  With __builtin_amdgcn_global_load_lds anywhere in a loop the compiler (ROCm 7.2) stops counting
+// its LDS waits: every s_waitcnt before an MFMA becomes lgkmcnt(0), which also waits for the fragments just requested for the NEXT
+// k-step, so the prefetch hides nothing (measured: 58 cycles per MFMA from a wave alone on its SIMD, 32 being the pipe's rate).
+// Issued this way the copy is invisible to that bookkeeping and the waits come out counted (lgkmcnt(2)).  The wave base address goes
+// to M0 (saved and restored: the compiler keeps its own idea of M0); completion is the caller's s_waitcnt vmcnt(0) + barrier, as before.
+__device__ __forceinline__ void lds_dma16(const void* src, const void* lds_dst) {
+    const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+// the same with a wave-uniform source base (SGPR pair) and a 32-bit lane offset: no address registers per piece
+__device__ __forceinline__ void lds_dma16_s(const void* src_uniform, unsigned lane_off, const void* lds_dst) {
+    const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(src_uniform), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* src, const void* lds_dst) {
+    const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
 template <int LAYOUT, bool FULLD>
 __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __restrict__ x, int64_t ldx, const unsigned char* __restrict__ rows_tab,
                                                               const float* __restrict__ en_tab, const float* __restrict__ cee,
@@ -70,20 +95,15 @@ __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __res
     const int ntiles = (K + kSTile - 1) / kSTile;
 
     // tile -> LDS: wave w copies code rows 8w .. 8w+7; waves 0 and 1 also the tile's 64 + 64 constants
+    const unsigned lane16 = lane * 16;
     auto copy_tile = [&](int tile, int buf) {
         unsigned char* dst = smem + buf * kSBufB;
         unsigned char* cst = smem + kSConst + (tile % 3) * kSSlotB;
-        const unsigned char* src = rows_tab + ((int64_t)tile * kSTile + wave * 8) * 1024 + lane * 16;
+        const unsigned char* src = rows_tab + ((int64_t)tile * kSTile + wave * 8) * 1024;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + (wave * 8 + r) * kSRowB), 16, 0, 0);
-        if (wave == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cee + tile * kSTile + lane),
-                                             (__attribute__((address_space(3))) void*)(cst), 4, 0, 0);
-        if (wave == 1)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(en_tab + tile * kSTile + lane),
-                                             (__attribute__((address_space(3))) void*)(cst + kSTile * 4), 4, 0, 0);
+        for (int r = 0; r < 8; ++r) lds_dma16_s(src + r * 1024, lane16, dst + (wave * 8 + r) * kSRowB);
+        if (wave == 0) lds_dma4(cee + tile * kSTile + lane, cst);
+        if (wave == 1) lds_dma4(en_tab + tile * kSTile + lane, cst + kSTile * 4);
     };
     copy_tile(0, 0);
 
@@ -271,31 +291,6 @@ __global__ __launch_bounds__(kSThreads) void vq_screen_kernel(const float* __res
             row_list[pos] = row;
         }
     }
-}
-
-// LDS-DMA through inline assembly.  With __builtin_amdgcn_global_load_lds anywhere in a loop the compiler (ROCm 7.2) stops counting
-// its LDS waits: every s_waitcnt before an MFMA becomes lgkmcnt(0), which also waits for the fragments just requested for the NEXT
-// k-step, so the prefetch hides nothing (measured: 58 cycles per MFMA from a wave alone on its SIMD, 32 being the pipe's rate).
-// Issued this way the copy is invisible to that bookkeeping and the waits come out counted (lgkmcnt(2)).  The wave base address goes
-// to M0 (saved and restored: the compiler keeps its own idea of M0); completion is the caller's s_waitcnt vmcnt(0) + barrier, as before.
-__device__ __forceinline__ void lds_dma16(const void* src, const void* lds_dst) {
-    const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-}
-// the same with a wave-uniform source base (SGPR pair) and a 32-bit lane offset: no address registers per piece
-__device__ __forceinline__ void lds_dma16_s(const void* src_uniform, unsigned lane_off, const void* lds_dst) {
-    const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(lane_off), "s"(src_uniform), "s"(dst) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(const void* src, const void* lds_dst) {
-    const unsigned dst = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_dst;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
 // ------------------------------------------------------------------------------------------ staggered, persistent form (D = 256)
