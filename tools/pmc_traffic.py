@@ -9,7 +9,7 @@ import sys
 
 root = sys.argv[1]
 E, C, T, S = 16384, 30, 1500, 375
-KERNEL = {"vq": "vq_argmin_dma_kernel", "vqs": "vq_screen_kernel", "vqb": "vq_bf16x6_kernel", "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1, 1, 256",
+KERNEL = {"vq": "vq_argmin_dma_kernel", "vqs": "vq_screen_pipe_kernel", "vqb": "vq_bf16x6_kernel", "conv3": "conv_wino3_kernel", "conv4": "conv_tile_kernel<1, 1, 256",
           "fir": "fir_fft_kernel", "welch_scaled": "welch_team_kernel", "affine_post": "affine_post_kernel"}
 OUTKEY = {"vqs": "vq_screen", "vqb": "vq_bf16x6"}     # bench.py looks the quantizer up as vq_<method>
 ALGO = {"vq": (256 * S * 4 + S * 8) * E, "vqs": (256 * S * 4 + S * 8) * E, "vqb": (256 * S * 4 + S * 8) * E, "conv3": (128 * S * 4 + 256 * S * 4) * E,
@@ -22,8 +22,9 @@ def mean_counter(d, kernel, counter):
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
             if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                vals.setdefault(r["Dispatch_Id"], 0.0)
-                vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
+                key = (fn, r["Dispatch_Id"])   # one file per profiled process: dispatch ids repeat across files
+                vals.setdefault(key, 0.0)
+                vals[key] += float(r["Counter_Value"])
     if not vals:
         return None
     return sum(vals.values()) / len(vals)
