@@ -587,7 +587,10 @@ def test_vq_bf16x6_golden_and_duplicates(shipped, vq_golden):
 
 
 @pytest.mark.parametrize("N,D,K", [(1000, 256, 512), (129, 256, 8192), (77, 64, 100), (300, 128, 65), (5, 72, 7), (128, 256, 1),
-                                   (4000, 248, 300), (20000, 256, 512)])
+                                   (4000, 248, 300), (20000, 256, 512),
+                                   # D = 256 is the persistent kernel: more than 2 x 256 blocks of 128 rows make its groups walk
+                                   # several blocks each (unevenly); one, two (ragged) and eight tiles per period
+                                   (140000, 256, 512), (70005, 256, 100), (66000, 256, 64)])
 def test_vq_screened_is_the_fp32_kernel_bit_for_bit(N, D, K):
     """lbm_vq_argmin_screened_f32 (bf16 screening pass with a rigorous bound + fp32 search of the unsettled rows): EXACTLY the
     indices of lbm_vq_argmin_f32, on spread-out rows, rows at and next to midpoints between codes, copies of codes, tiny and huge
