@@ -624,6 +624,10 @@ def test_vq_screened_is_the_fp32_kernel_bit_for_bit(N, D, K):
             assert nref <= N - N // 4        # and the spread-out rows are
         wide = torch.full((N, D + 8), float("nan"), device=DEV); wide[:, :D] = xd
         assert torch.equal(lbm_amd.vq_argmin(wide[:, :D], cbd, ee, no_xnorm=no_xnorm, split_tables=tab, screened=True), ref)
+        if N <= 20000:   # rows that start 4 bytes off a 16-byte boundary: the kernels' 4-byte load paths
+            flat = torch.empty(N * D + 1, device=DEV)
+            flat[1:] = xd.reshape(-1)
+            assert torch.equal(lbm_amd.vq_argmin(flat[1:].view(N, D), cbd, ee, no_xnorm=no_xnorm, split_tables=tab, screened=True), ref)
         if N % 5 == 0:
             S = N // 5
             zp = torch.full((5, D, S + 3), float("nan"), device=DEV)                           # pitched channel-major rows
