@@ -254,7 +254,13 @@ def parse_args(argv=None):
     ap.add_argument("--chunk", type=int, default=16384, help="epochs per pipeline launch")
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="epochs for the CPU baseline (0 = skip)")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="no exchange step at all (N = 1: no world-size-1 RCCL group either)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1: the exchange step of N > 1 (grouped all_gather of tokens / PSD / band features / keep mask on RCCL's "
+                         "stream + all_reduce of the histogram) runs inside the timed step against a world-size-1 RCCL group.  This is "
+                         "the DEFAULT at N = 1 with the nccl backend (so that a one-GPU box exercises the code path of config 4 and "
+                         "the step is the same at every N); the flag makes a failure to bring RCCL up fatal instead of falling back "
+                         "to a step without the exchange (recorded as `exchange_error`)")
     ap.add_argument("--gather-groups", type=int, default=16,
                     help="N > 1: the per-epoch outputs are all-gathered in this many groups of chunks, each group's exchange "
                          "running on the collective stream while the next group computes (1 = one exchange at the end of the step)")
@@ -430,6 +436,7 @@ def run_rank(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    exchange_error = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -437,6 +444,27 @@ def run_rank(args):
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    elif not args.no_gather and args.backend == "nccl":
+        # N = 1: a world-size-1 RCCL group, so that the exchange step below is the code that runs at N > 1 (communicator, RCCL's
+        # stream, async all_gather into [w, lo:hi] slices, int16 tokens as bytes, all_reduce) and not a short cut
+        try:
+            import socket
+            import torch.distributed as dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            probe = torch.ones(8, device=dev)
+            dist.all_reduce(probe)                       # the communicator is created lazily: bring it up (and fail) here
+            torch.cuda.synchronize()
+        except Exception as e:                           # noqa: BLE001  (whatever RCCL / the store raises)
+            if args.force_exchange:
+                raise
+            exchange_error = f"{type(e).__name__}: {e}"
+            if dist is not None and dist.is_initialized():
+                dist.destroy_process_group()
+            dist = None
 
     C, T, fs, K, D = (30, 1500, 500.0, args.codebook, 256) if args.shape == "S" else (64, 10000, 1000.0, args.codebook, 256)
     E, chunk = args.epochs, min(args.chunk, args.epochs)
@@ -466,7 +494,7 @@ def run_rank(args):
     xch = None
     nchunks = (E + chunk - 1) // chunk
     groups = max(1, min(args.gather_groups, nchunks))
-    if world > 1 and not args.no_gather:
+    if dist is not None and not args.no_gather:
         xch = Exchange(dist, args.backend, world, {"tokens": tokens, "psd": psd, "bandpower": bp, "keep": keep}, dev)
     # room left beside the resident input: allocator slack, RCCL's buffers and (N > 1) the flattened receive buffers torch
     # stages one group of each array through before it scatters them to the [w, lo:hi] slices
@@ -564,7 +592,8 @@ def run_rank(args):
     gather_ok = None
     if xch is not None:
         torch.cuda.synchronize()
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         g0.record()
         xch.gather_group(0, E)
@@ -680,6 +709,8 @@ def run_rank(args):
         if xch is not None:
             coll = ("all_gather(tokens int16 + PSD f32 + band features f32 + keep u8; %d groups, async on the collective stream)"
                     "+all_reduce(hist)" % groups)
+            if world == 1:
+                coll += " -- against a world-size-1 RCCL group (the N > 1 code path on this rank alone)"
         line = {
             "metric": "EEG epochs/sec (filter+ICA+PSD+VQ tokenize)",
             "value": round(world * E * args.steps / dt, 1),
@@ -695,7 +726,7 @@ def run_rank(args):
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
                        "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
-                       "collectives": coll, "backend": args.backend if world > 1 else None},
+                       "collectives": coll, "backend": args.backend if xch is not None else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "stages": stages,
@@ -703,6 +734,7 @@ def run_rank(args):
             "gather_ms_per_step": gather_ms,
             "gather_bytes_per_rank": (xch.bytes_per_epoch() * E) if xch is not None else None,
             "gather_order_ok": gather_ok,
+            "exchange_error": exchange_error,
             "variants": variants,
             "other_configs": extras,
         }
@@ -710,6 +742,7 @@ def run_rank(args):
         sys.stdout.flush()
     if world > 1:
         dist.barrier()   # rank 0 measured the per-stage events and variants alone: leave together
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -175,22 +175,25 @@ class Scaler:
         self.scale_ = (std if self.with_std else torch.ones_like(std)).to(torch.float32)
         return self
 
-    def fit(self, x: torch.Tensor, y=None, keep: Optional[torch.Tensor] = None, group=None, distributed: bool = False):
+    def fit(self, x: torch.Tensor, y=None, keep: Optional[torch.Tensor] = None, group=None, distributed: bool = False,
+            force: bool = False):
         """Per-channel statistics of the epochs handed in.  LOCAL by default: the reference fits one Scaler per file
         (multi-train/withpsd.py:267-270), and ranks that walk different files must not meet in a collective.
         With ``distributed=True`` (default group) or an explicit ``group`` the {sum, sum of squares, count} block is
         all-reduced first, so every rank fits the statistics of the whole job -- EVERY rank of the group
-        must then make the call, ranks with 0 epochs included (their moments are zeros)."""
+        must then make the call, ranks with 0 epochs included (their moments are zeros).  ``force``: run the all-reduce in
+        a group of one rank too (exercises RCCL on a one-GPU box)."""
         mom = self.moments(x, keep)
         if distributed or group is not None:
-            mom = self.reduce_moments(mom, group)
+            mom = self.reduce_moments(mom, group, force)
         return self.fit_from_moments(mom)
 
     @staticmethod
-    def reduce_moments(mom: torch.Tensor, group=None) -> torch.Tensor:
-        """Explicit all-reduce(SUM) of a [C, 3] moments block over ``group`` (no-op without an initialised process group)."""
+    def reduce_moments(mom: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+        """Explicit all-reduce(SUM) of a [C, 3] moments block over ``group`` (no-op without an initialised process group, or
+        in a group of one rank unless ``force``)."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=group)
         return mom
 

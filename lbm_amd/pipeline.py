@@ -284,11 +284,25 @@ def shard_range(E: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_epoch_outputs(local: torch.Tensor, group=None) -> torch.Tensor:
-    """all_gather of a per-epoch array [E_local, ...] whose E_local may differ between ranks.
-    Equal shards use one all_gather_into_tensor; unequal shards gather counts first, then padded blocks."""
+def _collective_needed(group, force: bool) -> bool:
+    """A collective runs when a process group exists and has more than one rank -- or, with ``force``, whenever a group
+    exists: a world-size-1 group still goes through RCCL's communicator, streams and buffers, which is how the exchange step
+    is exercised on a one-GPU box (tests/test_gpu_rccl_world1.py, ``bench.py`` at N = 1)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
+        if force:
+            raise RuntimeError("force=True needs an initialised torch.distributed process group")
+        return False
+    return force or dist.get_world_size(group) > 1
+
+
+def gather_epoch_outputs(local: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """all_gather of a per-epoch array [E_local, ...] whose E_local may differ between ranks.
+    Equal shards use one all_gather_into_tensor; unequal shards gather counts first, then padded blocks.
+    ``force`` runs the collectives even in a group of one rank (see ``_collective_needed``); ``force="padded"`` also takes
+    the padded-blocks route that unequal shards take."""
+    import torch.distributed as dist
+    if not _collective_needed(group, bool(force)):
         return local
     world = dist.get_world_size(group)
     n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
@@ -297,7 +311,7 @@ def gather_epoch_outputs(local: torch.Tensor, group=None) -> torch.Tensor:
     counts = [int(c.item()) for c in counts]
     mx = max(counts)
     local = local.contiguous()
-    if min(counts) == mx:
+    if min(counts) == mx and force != "padded":
         out = torch.empty((world * mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local, group=group)
         return out
@@ -309,11 +323,12 @@ def gather_epoch_outputs(local: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def gather_pipeline_outputs(out: Dict[str, torch.Tensor], group=None, names: Sequence[str] = ("tokens", "psd", "bandpower", "keep"),
-                            drop_rejected: bool = False) -> Dict[str, torch.Tensor]:
+                            drop_rejected: bool = False, force=False) -> Dict[str, torch.Tensor]:
     """The exchange step of the path: every per-epoch array of a rank's outputs all-gathered in rank order,
     i.e. the order np.concatenate gives the reference's per-batch lists (training/model.py:423, multi-train/withpsd.py:394-414).
     ``drop_rejected`` first removes the epochs whose keep flag is 0 (epochs.drop_bad, multi-train/withpsd.py:219): shards then
-    differ in length and the counts travel first (gather_epoch_outputs).  Every rank of the group must call this."""
+    differ in length and the counts travel first (gather_epoch_outputs).  Every rank of the group must call this.
+    ``force``: as in ``gather_epoch_outputs``."""
     sel = None
     if drop_rejected:
         sel = out["keep"].to(torch.bool)
@@ -321,14 +336,15 @@ def gather_pipeline_outputs(out: Dict[str, torch.Tensor], group=None, names: Seq
     for k in names:
         if k in out:
             v = out[k] if sel is None else out[k][sel]
-            res[k] = gather_epoch_outputs(v, group)
+            res[k] = gather_epoch_outputs(v, group, force)
     return res
 
 
-def allreduce_hist(hist: torch.Tensor, group=None) -> torch.Tensor:
-    """Sum of the K-entry codebook usage histogram over ranks (the only reduction of the path)."""
+def allreduce_hist(hist: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    """Sum of the K-entry codebook usage histogram over ranks (the only reduction of the path).  ``force``: run the
+    all-reduce in a group of one rank too."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_needed(group, force):
         dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
     return hist
 
