@@ -426,6 +426,22 @@ class Exchange:
         return o.reshape((-1,) + tuple(loc.shape[1:]))
 
 
+class _StdoutToStderr:
+    """File-descriptor-level redirect of stdout to stderr while RCCL comes up: it prints a version banner on fd 1, and this
+    program's stdout carries ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def run_rank(args):
     _import_product()
     rank = int(os.environ.get("RANK", "0"))
@@ -441,7 +457,10 @@ def run_rank(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", device_id=dev)
+                dist.all_reduce(torch.ones(8, device=dev))   # the communicator is created lazily: bring it up here
+                torch.cuda.synchronize()
         else:
             dist.init_process_group("gloo")
     elif not args.no_gather and args.backend == "nccl":
@@ -454,10 +473,10 @@ def run_rank(args):
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-            probe = torch.ones(8, device=dev)
-            dist.all_reduce(probe)                       # the communicator is created lazily: bring it up (and fail) here
-            torch.cuda.synchronize()
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                dist.all_reduce(torch.ones(8, device=dev))   # the communicator is created lazily: bring it up (and fail) here
+                torch.cuda.synchronize()
         except Exception as e:                           # noqa: BLE001  (whatever RCCL / the store raises)
             if args.force_exchange:
                 raise

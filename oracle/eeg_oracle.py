@@ -683,6 +683,37 @@ def vq_near_tie_ok(flat_input, codebook, idx_build, idx_ref) -> np.ndarray:
     return ok
 
 
+def vq_tokens_explained(z_ref, z_build, codebook, tok_build, tok_ref) -> np.ndarray:
+    """Reference-side form of the near-tie rule, for comparing a build's tokens with the REFERENCE's tokens when the two
+    quantizers saw slightly different inputs (the build's encoder output z_build differs from the reference's z_ref by fp32
+    rounding of the stages in front).  True where a row's tokens are equal or the mismatch is explained:
+
+    the reference chose b on z_ref, the build chose a on z_build = z_ref + dz.  Exactly,
+        d(z_build, a) - d(z_build, b) = [d(z_ref, a) - d(z_ref, b)] - 2 dz.(e_a - e_b),
+    so both choices are consistent iff the reference-side gap g = d64(z_ref, a) - d64(z_ref, b) satisfies
+        |g| <= tol_fp32 + 2 |dz.(e_a - e_b)|,
+    tol_fp32 = SURVEY.md 8(a)'s 8 eps (|z|^2 + |e|^2 + 2|z.e|) (the smaller of the two codes' values).  With z_build = None
+    (the build exposes no z) dz = 0: the plain near-tie rule on the reference's z.  Exact duplicate code rows are never
+    explained: the lowest index is required."""
+    zr = np.asarray(z_ref, dtype=np.float64)
+    zb = zr if z_build is None else np.asarray(z_build, dtype=np.float64)
+    e = np.asarray(codebook, dtype=np.float64)
+    a_all = np.asarray(tok_build).reshape(-1)
+    b_all = np.asarray(tok_ref).reshape(-1)
+    ok = a_all == b_all
+    eps = 2.0 ** -23
+    for i in np.nonzero(~ok)[0]:
+        a, b = int(a_all[i]), int(b_all[i])
+        if np.array_equal(e[a], e[b]):
+            continue
+        zz = float(zr[i] @ zr[i])
+        da = zz + e[a] @ e[a] - 2.0 * (zr[i] @ e[a])
+        db = zz + e[b] @ e[b] - 2.0 * (zr[i] @ e[b])
+        tol = 8 * eps * min(zz + e[a] @ e[a] + 2.0 * abs(zr[i] @ e[a]), zz + e[b] @ e[b] + 2.0 * abs(zr[i] @ e[b]))
+        ok[i] = abs(da - db) <= tol + 2.0 * abs((zb[i] - zr[i]) @ (e[a] - e[b]))
+    return ok
+
+
 def vq_forward(inputs, codebook, commitment_cost: float = 0.25):
     """``VectorQuantizerEMA.forward`` in eval mode (training/model.py:84-149).
 
@@ -726,6 +757,32 @@ def vqvae_encode(x, weights: dict):
     flat = np.ascontiguousarray(z.transpose(0, 2, 1)).reshape(-1, D)
     idx = vq_argmin(flat, weights["vq_layer.embedding.weight"])
     return idx.reshape(B, S), z
+
+
+def decoder_forward(q, weights: dict):
+    """``VQVAE.decoder`` (training/model.py:184-192): four ConvTranspose1d layers, ReLU after the first three.
+    weights: decoder.{0,2,4,6}.{weight,bias}.  q [B, D, S] -> [B, C, 4 S + 3]."""
+    import torch
+    import torch.nn.functional as F
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float32)  # noqa: E731
+    w = lambda i, n: t(weights[f"decoder.{i}.{n}"])  # noqa: E731
+    with torch.no_grad():
+        h = torch.as_tensor(np.asarray(q), dtype=torch.float32)
+        h = F.relu(F.conv_transpose1d(h, w(0, "weight"), w(0, "bias"), stride=1))
+        h = F.relu(F.conv_transpose1d(h, w(2, "weight"), w(2, "bias"), stride=1, padding=1))
+        h = F.relu(F.conv_transpose1d(h, w(4, "weight"), w(4, "bias"), stride=2, padding=1, output_padding=1))
+        h = F.conv_transpose1d(h, w(6, "weight"), w(6, "bias"), stride=2, padding=1, output_padding=1)
+    return h.numpy()
+
+
+def vqvae_forward(x, weights: dict, commitment_cost: float = 0.25):
+    """``VQVAE.forward`` in eval mode (training/model.py:195-203): encoder -> permute -> quantizer forward -> permute ->
+    decoder.  Returns (vq_loss, x_recon [B, C, 4 S + 3], perplexity, indices int64 [B, S])."""
+    z = encoder_forward(x, weights)
+    zp = np.ascontiguousarray(z.transpose(0, 2, 1))
+    loss, quant, perp, idx, _ = vq_forward(zp, weights["vq_layer.embedding.weight"], commitment_cost)
+    x_recon = decoder_forward(np.ascontiguousarray(quant.transpose(0, 2, 1)), weights)
+    return loss, x_recon, perp, idx
 
 
 def ema_update(codebook_state: dict, flat_input, idx, decay: float = 0.99, epsilon: float = 1e-5):

@@ -30,8 +30,8 @@ def main():
     m.load_state_dict(sd)
     m.eval()
 
-    # (1) shipped weights needed on the hot path (encoder + codebook + EMA buffers)
-    keep = {k: v.numpy() for k, v in sd.items() if k.startswith("encoder.") or k.startswith("vq_layer.")}
+    # (1) shipped weights needed on the hot path (encoder + codebook + EMA buffers) and by VQVAE.forward (decoder)
+    keep = {k: v.numpy() for k, v in sd.items() if k.startswith(("encoder.", "vq_layer.", "decoder."))}
     np.savez_compressed(os.path.join(OUT, "vq_vae_shipped.npz"), **keep)
     cb = sd["vq_layer.embedding.weight"].numpy()
     zero_rows = np.nonzero((cb == 0).all(1))[0]
@@ -55,6 +55,7 @@ def main():
         out["fwd_vq_loss"] = np.float32(vq_loss.item())
         out["fwd_perplexity"] = np.float32(perplexity.item())
         out["fwd_indices"] = indices.numpy()
+        out["fwd_x_recon"] = x_recon.numpy()
         zp = m.encoder(x).permute(0, 2, 1).contiguous()
         loss2, quant2, perp2, idx2 = m.vq_layer(zp)
         out["vqfwd_in"] = zp.numpy()

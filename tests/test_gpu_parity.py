@@ -29,6 +29,22 @@ def _need_gpu():
     _lib.load()
 
 
+MIN_TOKEN_AGREEMENT = 0.999
+
+
+def _assert_tokens(tok, ref, z_ref, cb, z_build=None, min_agree=MIN_TOKEN_AGREEMENT):
+    """Tokens against the reference's / oracle's: every mismatch must be explained on the REFERENCE-side z (oracle
+    vq_tokens_explained: fp32 near-tie rule + the exact effect of the build's own z differing from the reference's), and the
+    agreement must be what is measured (>= 0.999), not merely 'most'.  z arrays are [B, D, S] (channel-major) or flat [N, D]."""
+    flat = lambda z: None if z is None else (np.transpose(np.asarray(z), (0, 2, 1)).reshape(-1, np.asarray(z).shape[1])  # noqa: E731
+                                             if np.asarray(z).ndim == 3 else np.asarray(z))
+    tok, ref = np.asarray(tok).reshape(-1), np.asarray(ref).reshape(-1)
+    ok = orc.vq_tokens_explained(flat(z_ref), flat(z_build), cb, tok, ref)
+    agree = float((tok == ref).mean())
+    assert ok.all(), f"{int((~ok).sum())} unexplained token mismatches of {tok.size} (agreement {agree:.5f})"
+    assert agree >= min_agree, f"token agreement {agree:.5f} < {min_agree}"
+
+
 def _rms_ok(got, want, tol=1e-5):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
@@ -188,8 +204,9 @@ def test_scaler_matches_oracle():
 # inputs (test_welch_matches_oracle).  At the end of the chain its input already carries the fp32 rounding of the 825-tap FIR
 # (~1e-6 of the row rms per sample) and of the 30-channel ICA map (~1e-6): a PSD bin is quadratic in the signal, so those input
 # errors arrive doubled, and out-of-band-attenuated bins near 4 and 30 Hz sit 20-30 dB under the row maximum.  Measured on the
-# bench's config-1 sample: 0.05 of the stage tolerance; 2.0 is the bound asserted (round 1 allowed 4.0).
-PIPELINE_PSD_TOL = 2.0
+# bench's config-1 sample: 0.05 of the stage tolerance; 1.0 -- the stage tolerance itself, i.e. north_star's rtol 1e-5 -- is the
+# bound asserted (round 1 allowed 4.0, round 2 2.0).
+PIPELINE_PSD_TOL = 1.0
 
 
 def _psd_err(got, want):
@@ -488,7 +505,8 @@ def test_pipeline_fused_and_separate_dsp_fronts_agree(shipped, fuse):
     assert np.array_equal(out["keep"].cpu().numpy().astype(bool), want["keep"])
     assert _psd_err(out["psd"].cpu().numpy(), want["psd"]) <= PIPELINE_PSD_TOL
     assert float(np.abs(out["standardized"].cpu().numpy() - want["standardized"]).max()) <= 1e-4
-    assert (out["tokens"].cpu().numpy() == want["tokens"]).mean() >= 0.95
+    _assert_tokens(out["tokens"].cpu().numpy(), want["tokens"], want["z"], shipped["vq_layer.embedding.weight"],
+                   z_build=out["z"].cpu().numpy())
 
 
 # ------------------------------------------------------------------------------------------------ a12-a14 VQ
@@ -500,7 +518,7 @@ def test_vq_golden_get_code_indices(shipped, vq_golden):
     assert ok.all()
     assert (idx[:8] == 406).all()                      # exact ties among the 100 all-zero codes: lowest index
     assert (idx[8:16] == vq_golden["gci_idx"][8:16]).all()
-    assert (idx == vq_golden["gci_idx"]).mean() >= 0.97
+    assert (idx == vq_golden["gci_idx"]).mean() >= MIN_TOKEN_AGREEMENT
 
 
 def test_vq_duplicate_codes_lowest_index_wins():
@@ -719,14 +737,15 @@ def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
         z = lbm_amd.encoder_forward(x, m.encoder).permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
         # same-input near-tie rule (the encoder output differs from the CPU one by fp32 rounding)
         assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
-        assert (tok == ref).mean() >= 0.97
+        # against the reference's own tokens, judged on the reference's own z (golden)
+        _assert_tokens(tok, ref, vq_golden[f"z_{name}"], cb, z_build=z)
     # VectorQuantizerEMA.forward in eval mode (training/model.py:84-149)
     with torch.no_grad():
         loss, quant, perp, idx = m.vq_layer(torch.from_numpy(vq_golden["vqfwd_in"]).to(DEV))
     assert orc.vq_near_tie_ok(vq_golden["vqfwd_in"].reshape(-1, 256), cb, idx.cpu().numpy().reshape(-1),
                               vq_golden["vqfwd_indices"].reshape(-1)).all()
     same = idx.cpu().numpy() == vq_golden["vqfwd_indices"]
-    assert same.mean() >= 0.97
+    assert same.mean() >= MIN_TOKEN_AGREEMENT
     if same.all():
         np.testing.assert_allclose(quant.cpu().numpy(), vq_golden["vqfwd_quantized"], rtol=0, atol=0)
         np.testing.assert_allclose(float(loss), vq_golden["vqfwd_loss"], rtol=1e-5)
@@ -734,6 +753,37 @@ def test_vqvae_module_encode_and_forward_golden(shipped, vq_golden):
     # get_code_indices keeps the reference signature: flat [N, D] in, int64 [N] out
     gi = m.vq_layer.get_code_indices(torch.from_numpy(vq_golden["gci_in"]).to(DEV))
     assert gi.shape == (1024,) and gi.dtype == torch.int64
+
+
+def test_vqvae_forward_golden(shipped, vq_golden):
+    """VQVAE.forward in eval mode (training/model.py:195-203) against the imported reference's outputs on the shipped checkpoint
+    (oracle/gen_golden.py: fwd_vq_loss, fwd_perplexity, fwd_indices, fwd_x_recon).  The quantizer runs on the HIP kernels; the
+    encoder / decoder of this training-side entry point run through torch (training is off the hot path)."""
+    m = lbm_amd.VQVAE(30, 256, 512, 0.25, 0.99)
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys          # vq_vae_model.pth's keys, all of them
+    m = m.to(DEV).eval()
+    x = torch.from_numpy(vq_golden["x_P"]).to(DEV)
+    with torch.no_grad():
+        vq_loss, x_recon, perplexity, indices = m(x)
+    assert indices.shape == (4, 9) and indices.dtype == torch.int64 and x_recon.shape == (4, 30, 39)
+    idx = indices.cpu().numpy()
+    z = lbm_amd.encoder_forward(x, m.encoder).cpu().numpy()
+    _assert_tokens(idx, vq_golden["fwd_indices"], vq_golden["z_P"], shipped["vq_layer.embedding.weight"], z_build=z)
+    if np.array_equal(idx, vq_golden["fwd_indices"]):
+        np.testing.assert_allclose(float(vq_loss), float(vq_golden["fwd_vq_loss"]), rtol=1e-5)
+        np.testing.assert_allclose(float(perplexity), float(vq_golden["fwd_perplexity"]), rtol=1e-5)
+        ref = vq_golden["fwd_x_recon"]
+        assert float(np.abs(x_recon.cpu().numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max())
+    # the same call with gradients enabled (the training loop's forward, training/model.py:349): same numbers, differentiable
+    m.train(False)
+    xg = x.clone().requires_grad_(True)
+    l2, xr2, p2, i2 = m(xg)
+    assert torch.equal(i2, indices)
+    np.testing.assert_allclose(float(l2.detach()), float(vq_loss), rtol=1e-5)
+    assert float((xr2.detach() - x_recon).abs().max()) <= 2e-5 * float(x_recon.abs().max())
+    (l2 + xr2.square().mean()).backward()
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
 
 
 def test_vq_forward_tail_kernels_with_reference_indices(shipped, vq_golden):
@@ -792,7 +842,7 @@ def test_vq_ema_two_training_steps_use_the_updated_codebook(shipped, vq_golden):
     ref2 = orc.vq_argmin(flat2, w1)
     got2 = idx2.cpu().numpy().reshape(-1)
     assert orc.vq_near_tie_ok(flat2, w1, got2, ref2).all()
-    assert (got2 == ref2).mean() >= 0.97
+    assert (got2 == ref2).mean() >= MIN_TOKEN_AGREEMENT
     # what the round-1 bug computed: the NEW codebook with the OLD row norms.  It must differ from the right answer by
     # more than near-ties, or this test could not have caught it
     w0 = shipped["vq_layer.embedding.weight"].astype(np.float64)
@@ -831,7 +881,7 @@ def test_vqvae_encode_folded_projection_option(shipped, vq_golden):
         assert tok.shape == ref.shape and tok.dtype == np.int64
         zg = np.transpose(vq_golden[f"z_{name}"], (0, 2, 1)).reshape(-1, 256)
         assert orc.vq_near_tie_ok(zg, cb, tok.reshape(-1), ref.reshape(-1)).all()
-        assert (tok == ref).mean() >= 0.97
+        assert (tok == ref).mean() >= MIN_TOKEN_AGREEMENT
     f1 = m._folded_codebook()
     assert m._folded_codebook() is f1                       # cached
     with torch.no_grad():
@@ -846,7 +896,11 @@ def test_vqvae_encode_folded_projection_option(shipped, vq_golden):
     dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, torch.arange(70) % 3), batch_size=32)
     a, la = lbm_amd.encode_data_for_transformer(m, dl, torch.device(DEV), fold_projection=True)
     b_, lb = lbm_amd.encode_data_for_transformer(m, dl, torch.device(DEV))
-    assert a.shape == b_.shape == (70, 9) and np.array_equal(la, lb) and (a == b_).mean() >= 0.97
+    assert a.shape == b_.shape == (70, 9) and np.array_equal(la, lb)
+    zd = lbm_amd.encoder_forward(data.to(DEV), m.encoder).cpu().numpy()
+    # folded against unfolded on THIS test's perturbed model (every projection bias + 0.5 pushes z away from the live codes, where
+    # many codes are nearly equidistant): measured 0.981, every mismatch a documented near-tie of the unfolded z
+    _assert_tokens(a, b_, zd, m.vq_layer.embedding.weight.detach().cpu().numpy(), min_agree=0.98)
 
 
 def test_vq_ema_training_step_golden(shipped, vq_golden):
@@ -857,7 +911,7 @@ def test_vq_ema_training_step_golden(shipped, vq_golden):
     x = torch.from_numpy(vq_golden["ema_in"]).to(DEV)
     loss, quant, perp, idx = vq(x)
     same = (idx.cpu().numpy() == vq_golden["ema_idx"])
-    assert same.mean() >= 0.97
+    _assert_tokens(idx.cpu().numpy(), vq_golden["ema_idx"], vq_golden["ema_in"].reshape(-1, 256), shipped["vq_layer.embedding.weight"])
     if same.all():
         np.testing.assert_allclose(vq.ema_cluster_size.cpu().numpy(), vq_golden["ema_cluster_size"], rtol=1e-6)
         np.testing.assert_allclose(vq.ema_w.cpu().numpy(), vq_golden["ema_w"], rtol=1e-6, atol=1e-7)
@@ -903,8 +957,9 @@ def test_encode_data_for_transformer_signature(shipped):
     dl = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(data, labels), batch_size=lbm_amd.BATCH_SIZE)
     idx, lab = lbm_amd.encode_data_for_transformer(m, dl, torch.device(DEV))
     assert idx.shape == (150, 9) and idx.dtype == np.int64 and np.array_equal(lab, labels.numpy())
-    ref, _ = orc.vqvae_encode(data.numpy(), shipped)
-    assert (idx == ref).mean() >= 0.97
+    ref, z_ref = orc.vqvae_encode(data.numpy(), shipped)
+    _assert_tokens(idx, ref, z_ref, shipped["vq_layer.embedding.weight"],
+                   z_build=lbm_amd.encoder_forward(data.to(DEV), m.encoder).cpu().numpy())
 
 
 # ------------------------------------------------------------------------------------------------ whole pipeline
@@ -934,7 +989,7 @@ def test_pipeline_matches_oracle(shipped, T):
     z = out["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
     cb = shipped["vq_layer.embedding.weight"]
     assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
-    assert (tok == want["tokens"]).mean() >= 0.95
+    _assert_tokens(tok, want["tokens"], want["z"], cb, z_build=out["z"].cpu().numpy())
     assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=512))
 
 
@@ -1081,7 +1136,7 @@ def test_pipeline_config_L_matches_oracle():
     z = out["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
     cb = weights["vq_layer.embedding.weight"]
     assert orc.vq_near_tie_ok(z, cb, tok.reshape(-1), orc.vq_argmin(z, cb)).all()
-    assert (tok == want["tokens"]).mean() >= 0.95
+    _assert_tokens(tok, want["tokens"], want["z"], cb, z_build=out["z"].cpu().numpy())
     assert np.array_equal(out["hist"].cpu().numpy(), np.bincount(tok.reshape(-1), minlength=K))
 
 

@@ -45,6 +45,35 @@ def test_oracle_vq_forward_golden(shipped, vq_golden):
     assert np.array_equal(vq_golden["fwd_indices"], vq_golden["vqfwd_indices"])
 
 
+def test_oracle_vqvae_forward_golden(shipped, vq_golden):
+    """VQVAE.forward (training/model.py:195-203) restated in the oracle against the imported reference's outputs."""
+    loss, x_recon, perp, idx = orc.vqvae_forward(vq_golden["x_P"], shipped, 0.25)
+    assert np.array_equal(idx, vq_golden["fwd_indices"])
+    np.testing.assert_allclose(loss, vq_golden["fwd_vq_loss"], rtol=1e-6)
+    np.testing.assert_allclose(perp, vq_golden["fwd_perplexity"], rtol=1e-6)
+    assert x_recon.shape == vq_golden["fwd_x_recon"].shape == (4, 30, 39)
+    np.testing.assert_allclose(x_recon, vq_golden["fwd_x_recon"], rtol=0, atol=1e-6 * float(np.abs(vq_golden["fwd_x_recon"]).max()))
+
+
+def test_oracle_vq_tokens_explained_rule():
+    """The reference-side near-tie rule: equal tokens pass; a swap between two far codes fails; a swap that the build's own
+    z perturbation explains passes; duplicate code rows never do."""
+    rs = np.random.RandomState(0)
+    cb = rs.randn(16, 8)
+    cb[9] = cb[3]
+    z = cb[[1, 2, 3, 4]] + 0.01 * rs.randn(4, 8)
+    ref = np.array([1, 2, 3, 4])
+    assert orc.vq_tokens_explained(z, None, cb, ref, ref).all()
+    assert orc.vq_tokens_explained(z, None, cb, np.array([1, 2, 3, 5]), ref).tolist() == [True, True, True, False]
+    assert orc.vq_tokens_explained(z, None, cb, np.array([1, 2, 9, 4]), ref).tolist() == [True, True, False, True]   # duplicate row
+    mid = 0.5 * (cb[5] + cb[6])                      # equidistant from codes 5 and 6
+    zr = np.stack([mid + 1e-9 * (cb[5] - cb[6])])    # the reference side leans to 5
+    zb = np.stack([mid - 1e-6 * (cb[5] - cb[6])])    # the build side to 6, by more than fp32 rounding
+    assert orc.vq_tokens_explained(zr, zb, cb, np.array([6]), np.array([5])).all()
+    far = np.stack([mid + 1e-3 * (cb[5] - cb[6])])
+    assert not orc.vq_tokens_explained(far, far, cb, np.array([6]), np.array([5])).any()
+
+
 def test_oracle_ema_update_golden(shipped, vq_golden):
     state = {"ema_cluster_size": shipped["vq_layer.ema_cluster_size"], "ema_w": shipped["vq_layer.ema_w"]}
     flat = vq_golden["ema_in"].reshape(-1, 256)
