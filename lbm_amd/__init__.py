@@ -18,4 +18,6 @@ from .quantizer import (VectorQuantizerEMA, VQVAE, encode_data_for_transformer, 
 from .recording import (read_raw_eeglab, pick_eeg_channels, extract_events, pair_trials, vigilance_labels,  # noqa: F401
                         mne_events, preprocess_recording, preprocess_recording_withpsd,
                         process_unsupervised_recording)
+from .dataset import (classify_channels, preprocess_dataset_withpsd, process_unsupervised_dataset, withpsd_file,  # noqa: F401
+                      unsupervised_file, SkipFile)
 from .pipeline import EpochPipeline, PipelineConfig, shard_range, gather_epoch_outputs, gather_pipeline_outputs, allreduce_hist  # noqa: F401

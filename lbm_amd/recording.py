@@ -180,14 +180,17 @@ def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: flo
                                  reject: Optional[float] = 150e-6, psd_fmin: float = FILTER_LFREQ, psd_fmax: float = FILTER_HFREQ,
                                  psd_window: str = "hann") -> dict:
     """The per-file body of multi-train/withpsd.py (:96-283) on one continuous ``[C, T]`` recording: filter -> notch ->
-    ICA fit, EOG scoring (``eog``: the [T] signal of an EOG / frontal channel, :136-139) and ECG scoring (``ecg``: the [T] signal of
-    the ECG channel, ``find_bads_ecg(method='correlation', threshold='auto')``, :145), apply -> trials (10th-percentile baseline, :192) -> stimulus-locked epochs (:204) with baseline and
+    ICA fit, EOG scoring (``eog``: the [T] signal of an EOG / frontal channel, or [n, T] for several: the union of what each
+    finds, :136-139) and ECG scoring (``ecg``: the [T] signal of the ECG channel, ``find_bads_ecg(method='correlation',
+    threshold='auto')``, :145) -- both channels pass the same band-pass / notch first, as the script filters
+    ``picks=['eeg', 'eog', 'ecg']`` (:118-119) --, apply -> trials (10th-percentile baseline, :192) -> stimulus-locked epochs (:204) with baseline and
     peak-to-peak rejection (:213-219) -> Welch PSD per epoch (:236-250, n_fft = int(sfreq), half overlap, Hann) ->
     ``Scaler(scalings='mean')`` over the kept epochs (:267-270).
 
     Returns ``dict(time_epochs [E, C, Tw], psd_epochs [E, C, F], psd_freqs [F], labels [E], events, keep, ica)``;
     ``save_withpsd_outputs`` writes them under the reference's file names.
     """
+    import torch
     from . import _lib
     from .epochs import Scaler, epoch_post, make_epochs, n_baseline_samples
     from .fastica import find_bads_ecg, find_bads_eog, ica_fit
@@ -198,18 +201,24 @@ def preprocess_recording_withpsd(data, sfreq: float, annotations, *, l_freq: flo
     x = _lib.dev_f32(data)
     if x.dim() != 2:
         raise ValueError("preprocess_recording_withpsd: data must be [channels, samples]")
+    n_eeg = x.shape[0]
+    aux = [_lib.dev_f32(a, x.device).reshape(-1, x.shape[1]) for a in (eog, ecg) if a is not None]
+    n_eog = aux[0].shape[0] if eog is not None else 0
+    if aux and ica:                                                                    # picks=['eeg', 'eog', 'ecg']: one filter pass
+        x = torch.cat([x] + aux, dim=0)
     x = filter_data(x, sfreq, l_freq, h_freq)                                          # :118
     if notch is not None and notch < sfreq / 2.0:
         x = notch_filter(x, sfreq, notch)                                              # :119
+    x, aux_f = x[:n_eeg], x[n_eeg:]
     state = None
     if ica:
         state = ica_fit(x, n_components=n_components, method=ICA_METHOD, random_state=random_state, fit_params=ica_fit_params)
         bad = [int(i) for i in exclude]
-        if eog is not None:
-            idx, _ = find_bads_eog(state, x, eog, sfreq)                               # :136-139 (default threshold)
+        for ch in range(n_eog):
+            idx, _ = find_bads_eog(state, x, aux_f[ch], sfreq)                         # :136-139 (default threshold)
             bad.extend(idx)
         if ecg is not None:
-            idx, _ = find_bads_ecg(state, x, ecg, sfreq, method="correlation", threshold="auto")       # :145
+            idx, _ = find_bads_ecg(state, x, aux_f[n_eog], sfreq, method="correlation", threshold="auto")  # :145
             bad.extend(idx)
         state["exclude"] = sorted(set(bad))
         keys = ("unmixing", "mixing", "pca_components", "pca_mean", "pre_whitener", "n_components")
