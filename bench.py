@@ -93,6 +93,31 @@ def stage_report(acc, model):
     return stages
 
 
+ATTAINABLE_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: float4 copy, 79 % of the 8 TB/s spec
+ATTAINABLE_FP32_TFLOPS = 155.0   # same guide: back-to-back fp32 MFMA issue, 99 % of spec
+
+
+def chunk_roofline(stages, model):
+    """End-to-end roofline of one chunk: the time the stages would take at their bounding peaks -- algorithmic bytes / HBM rate for
+    the HBM-bound stages, EXECUTED flops / the peak of the unit they ran on for the matrix stages -- over the measured sum of the
+    stage times.  `frac` uses the spec peaks the per-stage fractions use (8 TB/s, 157.3 / 2500 TFLOP/s); `frac_attainable` the
+    measured ceilings of the hardware guide (6.29 TB/s, 155 TFLOP/s fp32; bf16 unchanged)."""
+    floor = floor_att = meas = 0.0
+    for name, st in stages.items():
+        m = model[name]
+        meas += st["ms"]
+        if m["bound"] == "hbm":
+            floor += m["bytes"] / (PEAK_HBM_GBS * 1e9) * 1e3
+            floor_att += m["bytes"] / (ATTAINABLE_HBM_GBS * 1e9) * 1e3
+        else:
+            fl, peak = m.get("exec_flops", m["flops"]), m.get("peak", PEAK_FP32_TFLOPS)
+            floor += fl / (peak * 1e12) * 1e3
+            floor_att += fl / ((ATTAINABLE_FP32_TFLOPS if "peak" not in m else peak) * 1e12) * 1e3
+    return {"measured_ms": round(meas, 4), "floor_ms": round(floor, 4), "frac": round(floor / meas, 4),
+            "floor_ms_attainable": round(floor_att, 4), "frac_attainable": round(floor_att / meas, 4),
+            "definition": "sum over stages of (algorithmic bytes / HBM peak | executed flops / matrix peak of the unit) / sum of measured stage times"}
+
+
 def _timed_chunks(pipe, x, n_epochs, chunk, reps=2):
     """ms for n_epochs walked in chunks over the (smaller) resident buffer x, HIP events on the launch stream."""
     R = x.shape[0]
@@ -715,7 +740,8 @@ def run_rank(args):
                 "frac": round(stages[dom][key] / peak, 4), "executed_frac": stages[dom].get("executed_frac"), "traffic": traffic,
                 "traffic_source": "stored counter run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, "
                                   "profiles/pmc_traffic.json), not measured in this process" if traffic is not None else None,
-                "launch": f"{chunk} epochs, {stages[dom]['ms']} ms"}
+                "launch": f"{chunk} epochs, {stages[dom]['ms']} ms",
+                "chunk": chunk_roofline(stages, model)}
         cpu = None
         extras = {}
         if world == 1 and args.cpu_sample > 0:

@@ -101,3 +101,17 @@ def test_stage_report_executed_flops_and_peaks():
     assert abs(vq["executed_tflops"] - 3 * vq["tflops"]) < 0.01 and vq["frac"] == vq["executed_frac"] == round(vq["executed_tflops"] / 2500.0, 4)
     assert abs(c3["frac"] - c3["tflops"] / bench.PEAK_FP32_TFLOPS) < 1e-4 and abs(c3["executed_frac"] - c3["frac"] * 2 / 3) < 1e-3
     assert w["bound"] == "hbm" and abs(w["frac"] - w["gbs"] / bench.PEAK_HBM_GBS) < 1e-4 and "executed_frac" not in w
+
+
+def test_chunk_roofline_is_floor_over_measured():
+    """`roofline.chunk`: one end-to-end fraction next to the dominant kernel's (HBM stages at their bytes, matrix stages at their
+    EXECUTED flops against the unit they ran on)."""
+    import bench
+    m = bench.stage_model(16384, 30, 1500, 825, 512, 256, 375, 750, 27, vq_method="screen")
+    ms = {"fir": 3.0, "affine_post": 1.5, "welch": 0.85, "conv3": 8.0, "vq": 4.7}
+    rep = bench.stage_report({k: [v] for k, v in ms.items()}, m)
+    c = bench.chunk_roofline(rep, m)
+    want = (m["fir"]["bytes"] + m["affine_post"]["bytes"] + m["welch"]["bytes"]) / 8e12 * 1e3 \
+        + m["conv3"]["exec_flops"] / 157.3e12 * 1e3 + m["vq"]["exec_flops"] / 2500e12 * 1e3
+    assert abs(c["floor_ms"] - want) < 1e-3 and abs(c["measured_ms"] - sum(ms.values())) < 1e-9
+    assert abs(c["frac"] - want / sum(ms.values())) < 1e-3 and c["floor_ms_attainable"] > c["floor_ms"] and 0 < c["frac"] < 1
