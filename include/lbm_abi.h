@@ -163,8 +163,11 @@ int lbm_channel_scale_f32(const float* x, float* y, const float* mean, const flo
 /* lbm_channel_moments_f32 without a workspace argument and without any allocation.  NO COUNTERPART IN THE REFERENCE: it
  * exists for callers that cannot allocate device memory around the call -- code under HIP graph capture, tight serving
  * loops, harnesses that forbid hipMalloc.  Same arguments (minus row_ws) and bit-identical moments; the E*C*2 doubles of
- * per-row partial sums live in a static device array inside the library (16 MiB, held by every GPU the library has run
- * this call on until the process ends), whose address is resolved once per device at the first call on that device.
+ * per-row partial sums live in a static device array inside the library (16 MiB; a file-scope __device__ array is part of
+ * the code object, so EVERY GPU that loads the library holds its copy until the process ends, whether or not this call was
+ * ever made there), whose address is resolved once per device at the FIRST call on that device: that first call takes a
+ * mutex and calls hipGetSymbolAddress (which may load the module) and is therefore NOT capture-safe -- make one warm-up
+ * call per device (E = 0 is enough) before capturing a graph; later calls only enqueue kernels.
  * Limit: E * C <= LBM_STATIC_MOMENTS_MAX_ROWS, otherwise LBM_EUNSUPPORTED (use lbm_channel_moments_f32).
  * All calls on one GPU share that array: calls that may overlap on one GPU (different streams, different threads) race --
  * serialise them.  The call itself makes no hipMalloc / hipFree and allocates nothing on the host. */
@@ -311,7 +314,10 @@ int lbm_vq_argmin_bf16x6_f32(const float* x, int64_t ldx, int32_t layout, int64_
  * lbm_vq_argmin_f32's own kernel code.  tables: lbm_vq_split_tables_init(codebook) (above); codebook / e_sqnorm / layout /
  * hist_or_null as for lbm_vq_argmin_f32 (no minimum-distance output).  workspace: lbm_vq_screen_workspace_bytes(N, K) bytes of
  * caller-owned, 8-byte aligned device memory; after the call its first int32 holds the number of rows pass 2 searched.
- * D a multiple of 8 and <= 256, N < 2^31. */
+ * D a multiple of 8 and <= 256, N < 2^31; with a histogram K <= 32768 (checked before anything is enqueued).
+ * The bound's one assumption beyond IEEE arithmetic: one bf16 MFMA accumulate errs by at most 16 x 2^-24 (|C| + sum|a b|), which is
+ * gfx950 behaviour AS MEASURED (tools/probe/mfma_acc_probe.hip: <= 7.8 on operands built against the adder), not a specified
+ * property -- on other silicon re-run the probe (and bench.py's screen_check compares every token of a step in every run). */
 size_t lbm_vq_screen_workspace_bytes(int64_t N, int32_t K);
 int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t layout, int64_t S, const float* codebook, const void* tables,
                                const float* e_sqnorm, int64_t* idx_out, unsigned long long* hist_or_null, void* workspace,

@@ -121,6 +121,25 @@ def ptr(t):
     return t.data_ptr()
 
 
+def on_tensor_device(fn):
+    """Decorator of the public array-in/array-out wrappers: run ``fn`` with the device of its first CUDA tensor argument
+    current, so that ``stream_ptr()`` / ``ptr()`` inside see that device -- a tensor on cuda:1 works while cuda:0 is current,
+    as with plain torch ops.  Arguments that are not CUDA tensors (arrays, CPU tensors: moved to the current device by the
+    wrapper) leave the current device alone."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index == torch.cuda.current_device():
+                    break
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
+
+
 def dev_f32(t, device=None) -> torch.Tensor:
     """Contiguous float32 CUDA tensor view/copy of ``t`` (torch tensor or array-like)."""
     if not isinstance(t, torch.Tensor):

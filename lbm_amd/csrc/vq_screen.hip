@@ -25,6 +25,8 @@
 //     again over the whole codebook by the fp32 kernel's own code.
 //
 // The pieces are those of vq_bf16.hip (bf16x6.h); the codebook comes pre-split in the caller-owned table.
+#include <atomic>
+
 #include "bf16x6.h"
 #include <type_traits>
 
@@ -563,6 +565,20 @@ int lbm_vq_hist_launch(const int64_t* idx, unsigned long long* hist, int64_t N, 
 int lbm_vq_refine_launch(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t S, const float* codebook, const float* e_sqnorm,
                          int64_t* idx_out, const int64_t* row_list, const int* row_count, int64_t N, int D, int K, hipStream_t st);
 
+namespace {
+// The opt-in to more than 64 KiB of dynamic LDS is a per-function, per-device attribute: set once, not on every call.
+int dyn_lds_once(const void* fn, int slot) {
+    static std::atomic<bool> done[4][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    if (dev >= 0 && done[slot][dev].load(std::memory_order_acquire)) return LBM_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
+    if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_screened_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (dev >= 0) done[slot][dev].store(true, std::memory_order_release);
+    return LBM_OK;
+}
+}  // namespace
+
 extern "C" size_t lbm_vq_screen_workspace_bytes(int64_t N, int32_t K) {
     if (N < 0 || K < 1) return 0;
     return 256 + (size_t)vq_tab_plan(K, 256).Kp * sizeof(float) + (size_t)N * sizeof(int64_t);
@@ -592,6 +608,7 @@ extern "C" int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t l
     LBM_REQUIRE(layout == LBM_VQ_ROWS || (int64_t)D * ldx < 0x7fffffffLL, LBM_EUNSUPPORTED,
                 "lbm_vq_argmin_screened_f32: D * ldx must be below 2^31");
     LBM_REQUIRE(N < 0x7fffffffLL, LBM_EUNSUPPORTED, "lbm_vq_argmin_screened_f32: N must be below 2^31 (row counter)");
+    LBM_REQUIRE(hist_or_null == nullptr || K <= 32768, LBM_EUNSUPPORTED, "lbm_vq_argmin_screened_f32: histogram supports K <= 32768");
     if (layout != LBM_VQ_ROWS) {   // floats spanned by the rows of one workgroup (32-bit lane offsets in the screening kernel)
         const int64_t span = ((int64_t)kSRows / S + 2) * D * ldx;
         LBM_REQUIRE(span < (1LL << 30), LBM_EUNSUPPORTED, "lbm_vq_argmin_screened_f32: a block of %d rows spans %lld floats (limit 2^30)", kSRows,
@@ -613,8 +630,8 @@ extern "C" int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t l
     int rc;
     if (D == 256) {   // persistent, two staggered groups per workgroup
         auto kp = layout == LBM_VQ_ROWS ? vq_screen_pipe_kernel<LBM_VQ_ROWS> : vq_screen_pipe_kernel<LBM_VQ_CHANNEL_MAJOR>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
-        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_screened_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        rc = dyn_lds_once(reinterpret_cast<const void*>(kp), layout == LBM_VQ_ROWS ? 0 : 1);
+        if (rc != LBM_OK) return rc;
         const int64_t nblk = (N + 127) / 128;
         int64_t grid = (nblk + 1) / 2;
         if (grid > 256) grid = 256;
@@ -623,8 +640,8 @@ extern "C" int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t l
         rc = lbm::check_launch("lbm_vq_argmin_screened_f32(screen)");
     } else {
         auto k = layout == LBM_VQ_ROWS ? vq_screen_kernel<LBM_VQ_ROWS, false> : vq_screen_kernel<LBM_VQ_CHANNEL_MAJOR, false>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
-        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_screened_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        rc = dyn_lds_once(reinterpret_cast<const void*>(k), layout == LBM_VQ_ROWS ? 2 : 3);
+        if (rc != LBM_OK) return rc;
         hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kSThreads), kSLds, st, x, ldx, tb + p.rows_off, en_tab, cee, e_sqnorm, idx_out,
                            row_list, row_count, N, D, K, vec_ok, S);
         rc = lbm::check_launch("lbm_vq_argmin_screened_f32(screen)");
@@ -632,9 +649,6 @@ extern "C" int lbm_vq_argmin_screened_f32(const float* x, int64_t ldx, int32_t l
     if (rc != LBM_OK) return rc;
     rc = lbm_vq_refine_launch(x, ldx, layout, no_xnorm, S, codebook, e_sqnorm, idx_out, row_list, row_count, N, D, K, st);
     if (rc != LBM_OK) return rc;
-    if (hist_or_null != nullptr) {
-        LBM_REQUIRE(K <= 32768, LBM_EUNSUPPORTED, "lbm_vq_argmin_screened_f32: histogram supports K <= 32768");
-        rc = lbm_vq_hist_launch(idx_out, hist_or_null, N, K, st);
-    }
+    if (hist_or_null != nullptr) rc = lbm_vq_hist_launch(idx_out, hist_or_null, N, K, st);   // K was checked with the other arguments
     return rc;
 }

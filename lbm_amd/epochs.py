@@ -20,6 +20,7 @@ def n_baseline_samples(tmin: float, sfreq: float, b_end: float = 0.0) -> int:
     return int(round((b_end - tmin) * sfreq)) + 1
 
 
+@_lib.on_tensor_device
 def make_epochs(raw: torch.Tensor, event_samples, tmin: float, tmax: float, sfreq: float, first_samp: int = 0):
     """Window extraction of ``mne.Epochs(raw, events, tmin=tmin, tmax=tmax)`` (training/preprocess.py:262-271).
 
@@ -70,6 +71,7 @@ def save_withpsd_outputs(prefix: str, time_epochs, psd_epochs, psd_freqs, labels
     return paths
 
 
+@_lib.on_tensor_device
 def epoch_post(x: torch.Tensor, *, n_baseline: int = 0, reject: Optional[float] = None, standardize: bool = False,
                eps: float = ZSCORE_EPSILON, inplace_baseline: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
@@ -90,6 +92,7 @@ def affine_post_supported(Cin: int, Cout: int, T: int) -> bool:
     return bool(_lib.load().lbm_affine_post_supported(int(Cin), int(Cout), int(T)))
 
 
+@_lib.on_tensor_device
 def affine_post(x: torch.Tensor, A, b=None, *, n_baseline: int = 0, reject: Optional[float] = None, standardize: bool = True,
                 eps: float = ZSCORE_EPSILON, want_base: bool = True):
     """ICA channel map + baseline + peak-to-peak keep mask + z-score in ONE pass over x[E, Cin, T] (``lbm_affine_post_f32``):
@@ -122,6 +125,7 @@ def affine_post(x: torch.Tensor, A, b=None, *, n_baseline: int = 0, reject: Opti
     return out
 
 
+@_lib.on_tensor_device
 def standardize_epochs(x: torch.Tensor, eps: float = ZSCORE_EPSILON) -> torch.Tensor:
     """(x - mean_t) / (std_t + eps) per epoch and channel (training/preprocess.py:282-287)."""
     x = _lib.dev_f32(x)
@@ -142,6 +146,7 @@ class Scaler:
         self.with_mean, self.with_std = with_mean, with_std
         self.mean_ = self.scale_ = self.moments_ = None
 
+    @_lib.on_tensor_device
     def moments(self, x: torch.Tensor, keep: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                 static_scratch: bool = False) -> torch.Tensor:
         """[C, 3] float64 {sum, sum of squares, count}: the quantity to all-reduce across ranks.
@@ -197,6 +202,7 @@ class Scaler:
             dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=group)
         return mom
 
+    @_lib.on_tensor_device
     def transform(self, x: torch.Tensor) -> torch.Tensor:
         x = _lib.dev_f32(x)
         E, Cc, T = x.shape

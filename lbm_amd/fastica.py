@@ -44,6 +44,7 @@ def _all_reduce(t: torch.Tensor, group) -> torch.Tensor:
     return t
 
 
+@_lib.on_tensor_device
 def ica_stats(z: torch.Tensor, W, fun: str = "logcosh", alpha: float = 1.0, T: Optional[int] = None, group=None):
     """One pass: ``gxt[i, j] = sum_t fun(y_i) z_j``, ``gsum[i] = sum_t fun'(y_i)``, ``y = W z`` (float64 sums).
 
@@ -68,6 +69,7 @@ def ica_stats(z: torch.Tensor, W, fun: str = "logcosh", alpha: float = 1.0, T: O
     return out[: n * n].reshape(n, n), out[n * n:]
 
 
+@_lib.on_tensor_device
 def channel_moments(x: torch.Tensor, group=None):
     """(sum_t x_c, sum_t x_c x_d) in float64 for a device ``[C, T]`` recording (identity pass, W = I)."""
     C = x.shape[0]
@@ -82,6 +84,7 @@ def _sym_decorrelation(W: np.ndarray) -> np.ndarray:
     return np.linalg.multi_dot([u * (1.0 / np.sqrt(s)), u.T, W])
 
 
+@_lib.on_tensor_device
 def fastica_parallel(z: torch.Tensor, w_init, *, fun: str = "logcosh", alpha: float = 1.0, tol: float = 1e-4,
                      max_iter: int = 1000, T_total: Optional[int] = None, group=None):
     """sklearn ``_ica_par`` with the data pass on the GPU.  ``z``: whitened ``[n, T]`` device tensor.
@@ -110,6 +113,7 @@ def _exp_var_ncomp(var: np.ndarray, n: float):
     return k, float(cvar[k - 1])
 
 
+@_lib.on_tensor_device
 def ica_fit(data, *, n_components=None, method: str = "fastica", random_state=97, max_iter="auto", fit_params=None,
             group=None) -> dict:
     """Fit on a ``[C, T]`` recording (NumPy or device tensor).  Returns the fitted attributes under the names
@@ -236,6 +240,7 @@ def _find_bads_ch(ica: dict, data, target, sfreq: float, threshold: float, l_fre
     return [int(i) for i in bad], scores
 
 
+@_lib.on_tensor_device
 def find_bads_eog(ica: dict, data, eog, sfreq: float, *, threshold: float = 3.0, l_freq: float = 1.0, h_freq: float = 10.0):
     """Components whose 1-10 Hz time course correlates with the (1-10 Hz) EOG signal: Pearson scores, iterative
     z-score outliers above ``threshold``, ordered by |score| (``ICA.find_bads_eog(measure='zscore')``,
@@ -247,6 +252,7 @@ def find_bads_eog(ica: dict, data, eog, sfreq: float, *, threshold: float = 3.0,
     return _find_bads_ch(ica, data, eog, sfreq, threshold, l_freq, h_freq)
 
 
+@_lib.on_tensor_device
 def find_bads_ecg(ica: dict, data, ecg, sfreq: float, *, method: str = "correlation", threshold="auto", l_freq: float = 8.0,
                   h_freq: float = 16.0, measure: str = "zscore"):
     """``ica.find_bads_ecg(raw, ch_name=ecg, method='correlation', threshold='auto')`` (multi-train/withpsd.py:145, also

@@ -116,6 +116,7 @@ def fir_fft_tables(taps_dev: torch.Tensor, T: int) -> Optional[torch.Tensor]:
     return tab
 
 
+@_lib.on_tensor_device
 def fir_apply(data, taps, pad: str = "reflect_limited", method: str = "auto"):
     """Apply symmetric odd-length FIR taps along the last axis of a CUDA/array tensor (fp32 on device).
 
@@ -146,6 +147,7 @@ def fir_apply(data, taps, pad: str = "reflect_limited", method: str = "auto"):
     return y.cpu().numpy().astype(np.float64) if was_numpy else y
 
 
+@_lib.on_tensor_device
 def filter_data(data, sfreq, l_freq, h_freq, *, l_trans_bandwidth="auto", h_trans_bandwidth="auto",
                 fir_design="firwin", phase="zero", fir_window="hamming", pad="reflect_limited"):
     """``mne.filter.filter_data`` equivalent (array in, array out) on the GPU."""
@@ -181,6 +183,7 @@ def notch_taps(sfreq, freqs, notch_widths=None, trans_bandwidth: float = 1.0, fi
     return [_compose(n_taps, fn, [int(g) for g in gain], fir_window)]
 
 
+@_lib.on_tensor_device
 def notch_filter(data, sfreq, freqs, *, notch_widths=None, trans_bandwidth=1.0, fir_design="firwin",
                  fir_window="hamming", pad="reflect_limited"):
     """``mne.filter.notch_filter`` equivalent (``raw.notch_filter(freqs=60.0, fir_design='firwin')``, training/preprocess.py:82,
@@ -194,6 +197,7 @@ def notch_filter(data, sfreq, freqs, *, notch_widths=None, trans_bandwidth=1.0, 
     return y.cpu().numpy().astype(np.float64) if was_numpy else y
 
 
+@_lib.on_tensor_device
 def resample(data, up: int = 1, down: int = 1):
     """``mne.filter.resample(data, up, down, npad='auto', window='boxcar', pad='reflect_limited')`` along the last axis
     (``raw.resample(250)`` at preprocessing_unsupervised.py:37 is ``resample(data, 250, 500)`` after reduction).

@@ -53,6 +53,7 @@ def average_reference_matrix(C: int) -> np.ndarray:
     return np.eye(C) - np.full((C, C), 1.0 / C)
 
 
+@_lib.on_tensor_device
 def affine_channels(data, A, b=None):
     """y[e,o,t] = sum_c A[o,c] x[e,c,t] + b[o] on the GPU.  data: [E, Cin, T] (or [Cin, T])."""
     was_numpy = not isinstance(data, torch.Tensor)
@@ -78,12 +79,14 @@ def affine_channels(data, A, b=None):
     return y.cpu().numpy().astype(np.float64) if was_numpy else y
 
 
+@_lib.on_tensor_device
 def ica_apply(data, *, unmixing, mixing, pca_components, pca_mean, pre_whitener, n_components, exclude=()):
     A, b = ica_projection(unmixing=unmixing, mixing=mixing, pca_components=pca_components, pca_mean=pca_mean,
                           pre_whitener=pre_whitener, n_components=n_components, exclude=exclude)
     return affine_channels(data, A, b)
 
 
+@_lib.on_tensor_device
 def ica_get_sources(data, *, unmixing, pca_components, pca_mean, pre_whitener, n_components):
     A, b = ica_sources_matrix(unmixing=unmixing, pca_components=pca_components, pca_mean=pca_mean,
                               pre_whitener=pre_whitener, n_components=n_components)

@@ -42,6 +42,7 @@ def welch_bins(sfreq: float, n_fft: int, fmin: float, fmax: float) -> Tuple[np.n
     return freqs[sel], int(sel[0]), int(sel[-1])
 
 
+@_lib.on_tensor_device
 def psd_array_welch(data, sfreq, fmin=0.0, fmax=np.inf, n_fft=256, n_overlap=0, n_per_seg=None,
                     window="hamming", average="mean", row_scale=None):
     """``mne.time_frequency.psd_array_welch`` equivalent.  Returns (psds[..., F] (or [..., F, nseg]), freqs[F]).
@@ -88,6 +89,7 @@ def psd_array_welch(data, sfreq, fmin=0.0, fmax=np.inf, n_fft=256, n_overlap=0, 
     return (out.cpu().numpy().astype(np.float64) if was_numpy else out), freqs
 
 
+@_lib.on_tensor_device
 def band_powers(psds, freqs, per_channel: bool = False, already_db: bool = False):
     """psds[E, C, F] -> [E, 6] (or [E, C, 6]) = theta, alpha, beta, beta/theta, alpha/beta, theta/beta
     (dB means and ratios of dB means, preprocessing_unsupervised.py:45-61)."""

@@ -17,6 +17,7 @@ from .constants import VQ_EMBEDDING_DIM
 
 
 # ------------------------------------------------------------------------------------------ functional layer
+@_lib.on_tensor_device
 def rownorm2(m: torch.Tensor) -> torch.Tensor:
     m = _lib.dev_f32(m)
     out = torch.empty((m.shape[0],), dtype=torch.float32, device=m.device)
@@ -45,6 +46,7 @@ def fold_projection(codebook, proj_weight, proj_bias=None):
     return (E @ W).to(torch.float32).contiguous().to(dev), c.to(torch.float32).contiguous().to(dev)
 
 
+@_lib.on_tensor_device
 def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
     """Device table of the codebook cut into three bf16 pieces per value (``lbm_vq_split_tables_init``), the form
     ``vq_argmin(..., split_tables=...)`` / ``lbm_vq_argmin_bf16x6_f32`` consume."""
@@ -59,6 +61,7 @@ def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
     return tab
 
 
+@_lib.on_tensor_device
 def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = None, *, channel_major: bool = False,
               return_min: bool = False, hist: torch.Tensor = None, no_xnorm: bool = False, split_tables: torch.Tensor = None,
               screened: bool = False, return_refined: bool = False):
@@ -118,6 +121,7 @@ def vq_argmin(x: torch.Tensor, codebook: torch.Tensor, e_sqnorm: torch.Tensor = 
     return (idx, mind) if return_min else idx
 
 
+@_lib.on_tensor_device
 def vq_gather_loss(x: torch.Tensor, codebook: torch.Tensor, idx: torch.Tensor, want_quantized: bool = True):
     """(quantized with straight-through arithmetic [N, D] or None, sum of squared error as a float64 scalar tensor)."""
     x = _lib.dev_f32(x)
@@ -130,6 +134,7 @@ def vq_gather_loss(x: torch.Tensor, codebook: torch.Tensor, idx: torch.Tensor, w
     return q, err
 
 
+@_lib.on_tensor_device
 def vq_ema_sums(flat_input: torch.Tensor, idx: torch.Tensor, K: int):
     """(dw [K, D] fp32, counts [K] int64): the segmented sums of training/model.py:109-110,122 (deterministic)."""
     x = _lib.dev_f32(flat_input)
@@ -149,6 +154,7 @@ def vq_ema_sums(flat_input: torch.Tensor, idx: torch.Tensor, K: int):
     return dw, counts
 
 
+@_lib.on_tensor_device
 def vq_ema_apply(ema_cluster_size: torch.Tensor, ema_w: torch.Tensor, weight: torch.Tensor, dw: torch.Tensor,
                  counts: torch.Tensor, decay: float, epsilon: float):
     """In-place EMA codebook update (training/model.py:109-126) on fp32 CUDA tensors."""
@@ -161,6 +167,7 @@ def vq_ema_apply(ema_cluster_size: torch.Tensor, ema_w: torch.Tensor, weight: to
                                                 float(epsilon), _lib.stream_ptr()), "lbm_vq_ema_apply_f32")
 
 
+@_lib.on_tensor_device
 def perplexity_from_hist(hist: torch.Tensor) -> torch.Tensor:
     """exp(-sum p log(p + 1e-10)), p = hist / sum(hist)  (training/model.py:142-144)."""
     out = torch.empty((1,), dtype=torch.float32, device=hist.device)
@@ -187,6 +194,7 @@ def pitched_empty(B: int, Cc: int, L: int, device) -> torch.Tensor:
     return torch.empty((B, Cc, _pitch4(L)), dtype=torch.float32, device=device)[:, :, :L]
 
 
+@_lib.on_tensor_device
 def conv_split_tables(weight: torch.Tensor) -> torch.Tensor:
     """Device table of conv weights [Cout, Cin, k] cut into three bf16 pieces per value (``lbm_conv1d_split_tables_init``),
     the form ``conv1d(..., split_tables=...)`` / ``lbm_conv1d_bf16x6_f32`` consume."""
@@ -202,6 +210,7 @@ def conv_split_tables(weight: torch.Tensor) -> torch.Tensor:
     return tab
 
 
+@_lib.on_tensor_device
 def conv_wino3_tables(weight: torch.Tensor) -> torch.Tensor:
     """Device table of the Winograd-transformed weights of a 3-tap, stride-1, padding-1 layer [Cout, Cin, 3]
     (``lbm_conv1d_wino3_tables_init``), the form ``conv1d(..., wino_tables=...)`` / ``lbm_conv1d_wino3_f32`` consume."""
@@ -216,6 +225,7 @@ def conv_wino3_tables(weight: torch.Tensor) -> torch.Tensor:
     return tab
 
 
+@_lib.on_tensor_device
 def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, stride: int = 1, padding: int = 0,
            relu: bool = False, pitched_out: bool = False, split_tables: torch.Tensor = None,
            wino_tables: torch.Tensor = None) -> torch.Tensor:
@@ -254,6 +264,7 @@ def conv1d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None, str
     return y
 
 
+@_lib.on_tensor_device
 def encoder_forward(x: torch.Tensor, enc: "nn.Sequential | dict", pitched_out: bool = False) -> torch.Tensor:
     """VQVAE.encoder (training/model.py:169-177) on the HIP conv kernel: [B, C, L] -> [B, D, L//4].
     Intermediate activations live in row-padded buffers (16-byte rows)."""
@@ -299,6 +310,7 @@ class VectorQuantizerEMA(nn.Module):
         """Indices for an encoder output z[B, D, S] without the permute/contiguous copy."""
         return vq_argmin(z.detach(), self.embedding.weight.detach(), self._e_sqnorm(), channel_major=True, hist=hist)
 
+    @_lib.on_tensor_device
     def forward(self, inputs):
         input_shape = inputs.shape
         flat_input = inputs.reshape(-1, self.embedding_dim)
@@ -389,6 +401,7 @@ class VQVAE(nn.Module):
         return self._screen_tab
 
     @torch.no_grad()
+    @_lib.on_tensor_device
     def encode(self, x, hist=None, fold_projection: bool = False, screened: bool = False):
         """Input x[B, C, L] -> code indices int64 [B, L//4] (training/model.py:206-214), all on HIP kernels;
         the encoder output is consumed channel-major, so the permute(0,2,1).contiguous() copy disappears.

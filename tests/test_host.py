@@ -184,3 +184,47 @@ def test_conv_wino3_table_sizes_and_arguments():
     assert lib.lbm_conv1d_wino3_f32(None, 376, None, None, None, 376, 4, 128, 375, 256, 1, None) == -1     # NULL pointers
     assert lib.lbm_conv1d_wino3_f32(None, 376, None, None, None, 376, 4, 30, 375, 256, 1, None) == -2      # Cin % 8
     assert lib.lbm_conv1d_wino3_f32(None, 100, None, None, None, 376, 4, 128, 375, 256, 1, None) == -1     # pitch < row
+
+
+def test_wrappers_run_on_the_device_of_their_tensor(monkeypatch):
+    """a tensor on cuda:1 while cuda:0 is current must work as with plain torch ops -- the public wrappers switch to the
+    device of their first CUDA tensor argument (no GPU needed here: torch.cuda's device calls are stubbed)."""
+    import torch
+    from lbm_amd import _lib as L
+    state = {"cur": 0, "entered": []}
+
+    class FakeDeviceCtx:
+        def __init__(self, dev):
+            self.idx = dev.index
+        def __enter__(self):
+            self.prev, state["cur"] = state["cur"], self.idx
+            state["entered"].append(self.idx)
+        def __exit__(self, *a):
+            state["cur"] = self.prev
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["cur"])
+    monkeypatch.setattr(torch.cuda, "device", FakeDeviceCtx)
+
+    class FakeTensor(torch.Tensor):
+        pass
+
+    def fake(idx):
+        t = FakeTensor()
+        t.__class__ = type("T", (FakeTensor,), {"is_cuda": property(lambda s: True), "device": property(lambda s: torch.device("cuda", idx))})
+        return t
+
+    seen = []
+
+    @L.on_tensor_device
+    def wrapper(a, b=None, *, k=None):
+        seen.append(state["cur"])
+        return "r"
+
+    assert wrapper(fake(1)) == "r" and seen == [1] and state["cur"] == 0            # switched for the call, restored after it
+    assert wrapper(fake(0)) == "r" and seen == [1, 0] and state["entered"] == [1]      # already current: no switch
+    assert wrapper(None, k=fake(2)) == "r" and seen[-1] == 2                           # keyword tensors count
+    assert wrapper("array-like") == "r" and seen[-1] == 0                              # no CUDA tensor: the current device
+    import lbm_amd
+    for fn in (lbm_amd.vq_argmin, lbm_amd.conv1d, lbm_amd.psd_array_welch, lbm_amd.affine_post, lbm_amd.filter_data, lbm_amd.ica_apply,
+               lbm_amd.Scaler.moments, lbm_amd.Scaler.transform, lbm_amd.VQVAE.encode, lbm_amd.vq_split_tables):
+        assert hasattr(fn, "__wrapped__"), fn

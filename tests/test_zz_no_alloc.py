@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 MAX_ROWS = 1 << 20
 
 
-def _both(lib, x, keep):
+def _both(lib, x, keep, check_driver_memory=False):
     E, C, T = x.shape
     st = _lib.stream_ptr()
     ws = torch.full((max(E * C, 1), 2), float("nan"), dtype=torch.float64, device=x.device)
@@ -24,9 +24,15 @@ def _both(lib, x, keep):
     assert lib.lbm_channel_moments_f32(_lib.ptr(x), kp, _lib.ptr(ws), _lib.ptr(want), E, C, T, st) == 0
     torch.cuda.synchronize()
     before = torch.cuda.memory_allocated()
+    free_before, _ = torch.cuda.mem_get_info()
     assert lib.lbm_channel_moments_static_f32(_lib.ptr(x), kp, _lib.ptr(got), E, C, T, st) == 0, lib.lbm_last_error()
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    if check_driver_memory:
+        # torch's counter cannot see a hipMalloc made inside the library; the driver's free-memory figure can.  Asked
+        # only of a call AFTER the first on this device (the first resolves the symbol address and may load the module)
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after >= free_before, (free_before, free_after)
     return got.cpu().numpy(), want.cpu().numpy()
 
 
@@ -45,7 +51,7 @@ def test_static_scratch_moments_match_workspace_entry_point_twice():
     np.testing.assert_allclose(got1[:, 1], (ref * ref).sum(dim=(0, 2)).cpu().numpy(), rtol=1e-9)
     # call 2, right after, SMALLER: the scratch still holds call 1's partial sums beyond row 7*5
     x2 = torch.randn((7, 5, 333), generator=g, device="cuda")
-    got2, want2 = _both(lib, x2, None)
+    got2, want2 = _both(lib, x2, None, check_driver_memory=True)
     assert np.array_equal(got2, want2)
     np.testing.assert_allclose(got2[:, 0], x2.double().sum(dim=(0, 2)).cpu().numpy(), rtol=1e-9, atol=1e-9)
     assert (got2[:, 2] == 7 * 333).all()
