@@ -31,13 +31,17 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kThreads = 256;
 constexpr int BN = 128;
 
-template <int KS, int STRIDE, int BM>
+// PM = 32-position MFMA sub-tiles per wave: the workgroup tile is 64 PM positions (2 waves along the positions).  PM = 2 is the
+// 128-position tile every layer runs with.  Round 3 measured PM = 3 / 4 on the stride-2 layers (192 / 256 positions per tile, to spread the
+// fixed per-tile cost the stamps show: profiles/r03_experiments.md): conv1 2.39 -> 2.35 ms, conv2 3.61 -> 3.59 ms, i.e. within noise; not used.
+template <int KS, int STRIDE, int BM, int PM = 2>
 struct ConvCfg {
+    static constexpr int BN = 64 * PM;                   // positions per workgroup tile
     static constexpr int CK = (KS == 1) ? 16 : 8;        // input channels per chunk
     static constexpr int KC = CK * KS;                   // GEMM-K per chunk (16 / 24 / 32)
     static constexpr int LDA = KC + 4;                   // padded weight-slab row (conflict-free ds_read_b128)
     static constexpr int PADMAX = (KS == 1) ? 0 : 4;     // the window starts 4 samples early when pad > 0 (pad <= 4)
-    static constexpr int XW = ((BN - 1) * STRIDE + KS + PADMAX + 3) & ~3;   // window samples per channel row
+    static constexpr int XW = ((BN - 1) * STRIDE + KS + PADMAX + 3) & ~3;   // window samples per channel row (BN: this struct's)
     static constexpr int X4 = XW / 4;
     static constexpr int A_F4 = BM * KC / 4 / kThreads;  // weight float4 per thread per chunk
     static constexpr int X_F4 = (CK * X4 + kThreads - 1) / kThreads;   // input quads per thread per chunk
@@ -53,13 +57,13 @@ __device__ __forceinline__ float4 load_quad(const float* p, int o0, int o1, int 
     else return make_float4(p[o0], p[o1], p[o2], p[o3]);
 }
 
-template <int KS, int STRIDE, int BM, int VEC>
+template <int KS, int STRIDE, int BM, int VEC, int PM = 2>
 __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ y,
                                                              int Cin, int Lin, int ldx, int Cout, int Lout, int ldy,
                                                              int pad, int relu, int ptiles, int mtiles) {
-    using Cfg = ConvCfg<KS, STRIDE, BM>;
-    constexpr int CK = Cfg::CK, KC = Cfg::KC, LDA = Cfg::LDA, XW = Cfg::XW, X4 = Cfg::X4, CN = Cfg::CN;
+    using Cfg = ConvCfg<KS, STRIDE, BM, PM>;
+    constexpr int CK = Cfg::CK, KC = Cfg::KC, LDA = Cfg::LDA, XW = Cfg::XW, X4 = Cfg::X4, CN = Cfg::CN, BN = Cfg::BN;
     extern __shared__ __align__(16) float smem[];
     float* const s_a0 = smem;                 // 2 x [BM][LDA]   weights
     float* const s_x0 = smem + 2 * BM * LDA;  // 2 x [CK][XW]    input windows
@@ -163,16 +167,16 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
         }
     };
 
-    f32x16 acc[2][CN];   // [position sub-tile][channel sub-tile]
+    f32x16 acc[PM][CN];   // [position sub-tile][channel sub-tile]
 #pragma unroll
-    for (int pm = 0; pm < 2; ++pm)
+    for (int pm = 0; pm < PM; ++pm)
 #pragma unroll
         for (int cn = 0; cn < CN; ++cn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[pm][cn][r] = 0.f;
 
     // k-steps [4*qlo, 4*qhi) of this lane half's list, from LDS image `buf`
-    const int xsh = (wn * 64 + j) * STRIDE + (pada - pad);
+    const int xsh = (wn * (32 * PM) + j) * STRIDE + (pada - pad);
     auto mfma_block = [&](int buf, int qlo, int qhi) {
         const float* wp = s_a0 + buf * (BM * LDA) + (wm * (BM / 2) + j) * LDA + h * (KC / 2);
         const float* xp = s_x0 + buf * (CK * XW) + (h * (CK / 2)) * XW + xsh;
@@ -188,13 +192,14 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
             for (int u = 0; u < 4; ++u) {
                 const int s = 4 * q + u;            // k-step inside this lane half's list
                 const int ci = s / KS, kt = s % KS;  // compile-time after unrolling
-                const float x0 = xp[ci * XW + kt];
-                const float x1 = xp[ci * XW + kt + 32 * STRIDE];
+                float xs[PM];
 #pragma unroll
-                for (int cn = 0; cn < CN; ++cn) {
-                    acc[0][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, wv[cn][u], acc[0][cn], 0, 0, 0);
-                    acc[1][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, wv[cn][u], acc[1][cn], 0, 0, 0);
-                }
+                for (int pm = 0; pm < PM; ++pm) xs[pm] = xp[ci * XW + kt + pm * 32 * STRIDE];
+#pragma unroll
+                for (int cn = 0; cn < CN; ++cn)
+#pragma unroll
+                    for (int pm = 0; pm < PM; ++pm)
+                        acc[pm][cn] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[pm], wv[cn][u], acc[pm][cn], 0, 0, 0);
             }
         }
     };
@@ -230,10 +235,10 @@ __global__ __launch_bounds__(kThreads) void conv_tile_kernel(const float* __rest
         if (co >= Cout) continue;
         float* yr = yb + (int64_t)co * ldy;
 #pragma unroll
-        for (int pm = 0; pm < 2; ++pm) {
+        for (int pm = 0; pm < PM; ++pm) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int p = p0 + wn * 64 + pm * 32 + 8 * rq + 4 * h;
+                const int p = p0 + wn * (32 * PM) + pm * 32 + 8 * rq + 4 * h;
                 const float v0 = fmaxf(acc[pm][cn][4 * rq + 0] + bv[cn], lo), v1 = fmaxf(acc[pm][cn][4 * rq + 1] + bv[cn], lo);
                 const float v2 = fmaxf(acc[pm][cn][4 * rq + 2] + bv[cn], lo), v3 = fmaxf(acc[pm][cn][4 * rq + 3] + bv[cn], lo);
                 if constexpr (VEC == 4) {
@@ -583,17 +588,17 @@ __global__ __launch_bounds__(kThreads) void conv1d_generic_kernel(const float* _
     }
 }
 
-template <int KS, int STRIDE, int BM>
+template <int KS, int STRIDE, int BM, int PM = 2>
 int launch_tile(const float* x, const float* w, const float* bias, float* y, int64_t B, int Cin, int Lin, int64_t ldx, int Cout,
                 int Lout, int64_t ldy, int pad, int relu, hipStream_t st) {
-    using Cfg = ConvCfg<KS, STRIDE, BM>;
-    const int ptiles = (Lout + BN - 1) / BN;
+    using Cfg = ConvCfg<KS, STRIDE, BM, PM>;
+    const int ptiles = (Lout + Cfg::BN - 1) / Cfg::BN;
     const int mtiles = (Cout + BM - 1) / BM;
     const int64_t blocks = B * ptiles * mtiles;
     if (blocks > 0x7fffffffLL) return lbm::fail(LBM_EUNSUPPORTED, "lbm_conv1d_f32: grid too large");
     const size_t lds = Cfg::LDS_FLOATS * sizeof(float);
     const bool vec = (ldx % 4 == 0) && (ldy % 4 == 0) && ldx >= 4 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-    auto k = vec ? conv_tile_kernel<KS, STRIDE, BM, 4> : conv_tile_kernel<KS, STRIDE, BM, 1>;
+    auto k = vec ? conv_tile_kernel<KS, STRIDE, BM, 4, PM> : conv_tile_kernel<KS, STRIDE, BM, 1, PM>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_conv1d_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
