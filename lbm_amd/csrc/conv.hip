@@ -22,7 +22,11 @@
 //   outside the instantiations above.
 // fp32 MFMA = exact fp32 fmaf chain; summation order: chunks ascending, inside a chunk the two lane
 // halves own the first/second half of the chunk's (ci, kt) list in ascending order.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
+#include "conv_ws.h"
 
 namespace {
 
@@ -699,5 +703,10 @@ extern "C" int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tab
     if (B == 0) return LBM_OK;
     LBM_REQUIRE(x && tables && y, LBM_EINVAL, "lbm_conv1d_wino3_f32: NULL pointer");
     LBM_REQUIRE(((uintptr_t)tables & 15) == 0, LBM_EINVAL, "lbm_conv1d_wino3_f32: tables must be 16-byte aligned");
+    // Cin = 128 with 16-byte rows (the encoder's layer): the weights-stationary form (conv_wino_ws.hip), bit-identical results.
+    // LBM_WINO3_KERNEL=tile (read once) keeps the tile kernel for A/B measurements.
+    static const bool ws_off = [] { const char* v = getenv("LBM_WINO3_KERNEL"); return v != nullptr && strcmp(v, "tile") == 0; }();
+    if (!ws_off && lbm::wino3_ws_eligible(x, ldx, y, ldy, Cin, Cout))
+        return lbm::launch_wino3_ws(x, static_cast<const float*>(tables), bias, y, B, Lin, ldx, Cout, ldy, relu, lbm::as_stream(stream));
     return launch_wino3(x, static_cast<const float*>(tables), bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, relu, lbm::as_stream(stream), true);
 }

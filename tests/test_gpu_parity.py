@@ -386,6 +386,39 @@ def test_conv1d_wino3_table_is_bitwise_the_default_kernel(B, Cin, L, Cout):
         lbm_amd.conv1d(x, w, b, 2, 1, True, wino_tables=tab)
 
 
+@pytest.mark.parametrize("B,L,ld,Cout", [(3, 375, 376, 256), (100, 375, 376, 256), (77, 250, 252, 256), (2, 100, 100, 256), (2, 128, 128, 64),
+                                         (3, 129, 132, 192), (2, 136, 140, 256), (2, 2500, 2500, 256), (1, 3, 4, 64), (5, 1001, 1004, 128)])
+def test_conv1d_wino3_ws_is_the_tile_kernel_bit_for_bit(B, L, ld, Cout):
+    """Cin = 128 with 16-byte rows: lbm_conv1d_wino3_f32 runs the weights-stationary kernel (csrc/conv_wino_ws.hip: persistent workgroups,
+    a transform and 32 channels per wave, windows by LDS-DMA, exchange through LDS).  Same products in the same order as the tile kernel
+    (lbm_conv1d_pitched_f32), so: equal bit for bit -- one tile, many tiles per workgroup (B = 100: 300 tiles over 64 streams), rows that
+    end inside a quad, NaN in the pitch padding, with / without bias and ReLU, on a side stream -- and within 1e-5 of float64."""
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(B * 7 + L)
+    x = torch.randn(B, 128, ld, generator=g).to(DEV)
+    x[..., L:] = float("nan")
+    w = (torch.randn(Cout, 128, 3, generator=g) / math.sqrt(384)).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    tab = lbm_amd.conv_wino3_tables(w)
+    side = torch.cuda.Stream()
+    for relu, bias in ((1, b), (0, None)):
+        y0 = torch.full((B, Cout, ld), -7.0, device=DEV)
+        y1 = torch.full((B, Cout, ld), -7.0, device=DEV)
+        bp = p(bias) if bias is not None else None
+        assert lib.lbm_conv1d_pitched_f32(p(x), ld, p(w), bp, p(y0), ld, B, 128, L, Cout, 3, 1, 1, relu, None) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            assert lib.lbm_conv1d_wino3_f32(p(x), ld, p(tab), bp, p(y1), ld, B, 128, L, Cout, relu, _lib.stream_ptr()) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(y0[..., :L], y1[..., :L])
+        assert not torch.isnan(y1[..., :L]).any()
+        if ld - (L + 3) // 4 * 4 > 0:      # columns past the last quad of a row are never written
+            assert bool((y1[..., (L + 3) // 4 * 4:] == -7.0).all())
+        ref = torch.nn.functional.conv1d(x[..., :L].double().cpu(), w.double().cpu(), bias.double().cpu() if bias is not None else None, padding=1)
+        ref = ref.relu() if relu else ref
+        assert float((y1[..., :L].double().cpu() - ref).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 30, 1500, 64, 4, 2, 1), (2, 64, 750, 128, 4, 2, 1), (2, 128, 375, 256, 3, 1, 1),
                                                 (2, 256, 375, 256, 1, 1, 0), (2, 12, 130, 40, 3, 1, 1), (1, 20, 9, 7, 1, 1, 0)])
 def test_conv1d_pitched_rows_bitwise_equal_dense(B, Cin, L, Cout, k, s, p):
