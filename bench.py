@@ -44,7 +44,7 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine_post": "affine_post_kernel<1,6,true>", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_team_kernel<2,1>",
-                   "bandpower": "bandpower_kernel", "conv1": "conv_tile_kernel<4,2,64>", "conv2": "conv_tile_kernel<4,2,128>",
+                   "bandpower": "bandpower_kernel", "conv1": "conv_k4s2_ws_kernel<30,2>", "conv2": "conv_k4s2_ws_kernel<64,4>",
                    "conv3": "conv_wino3_ws_kernel", "conv4": "conv_tile_kernel<1,1,256>", "vq": "vq_argmin_dma_kernel"}
 KERNEL_OF_VQ = {"fp32": "vq_argmin_dma_kernel", "bf16x6": "vq_bf16x6_kernel", "screen": "vq_screen_pipe_kernel<1> (+ vq_argmin_kernel<256,1,true> on the unsettled rows)"}
 

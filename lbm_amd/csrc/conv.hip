@@ -648,6 +648,11 @@ extern "C" int lbm_conv1d_pitched_f32(const float* x, int64_t ldx, const float* 
     hipStream_t st = lbm::as_stream(stream);
     const bool w_vec = (((uintptr_t)w & 15) == 0) && ((Cin * ksize) % 4 == 0);
     const int ck = ksize == 1 ? 16 : 8;   // ConvCfg::CK: a ragged last chunk is shifted, which needs Cin >= CK
+    // the encoder's two 4-tap stride-2 layers with 16-byte rows: weights-stationary form (conv_k4s2_ws.hip), bit-identical results.
+    // LBM_K4S2_KERNEL=tile (read once) keeps the tile kernel for A/B measurements.
+    static const bool k4_ws_off = [] { const char* v = getenv("LBM_K4S2_KERNEL"); return v != nullptr && strcmp(v, "tile") == 0; }();
+    if (!k4_ws_off && ksize == 4 && stride == 2 && pad == 1 && lbm::k4s2_ws_eligible(x, ldx, w, y, ldy, Cin, Cout, Lin))
+        return lbm::launch_k4s2_ws(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, relu, st);
     if (w_vec && Cin >= ck && pad <= (ksize == 1 ? 0 : 4)) {
         if (ksize == 4 && stride == 2 && Cout <= 64) return launch_tile<4, 2, 64>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);
         if (ksize == 4 && stride == 2) return launch_tile<4, 2, 128>(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, pad, relu, st);

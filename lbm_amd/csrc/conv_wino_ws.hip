@@ -52,8 +52,9 @@ static_assert(kPieces * 256 == kHalfFloats, "a half window must be a whole numbe
 // address, wave-uniform LDS destination through M0 (saved and restored).
 __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_dst) {
     unsigned keep;
+    // (readfirstlane: under scalar-register pressure hipcc has handed this wave-uniform value to the "s" operand in a VGPR)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+                 : "=&s"(keep) : "v"(src), "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
 }
 
 // Source of the window quads that lie wholly outside [0, Lin) (the convolution's zero padding and everything right of a row's end)

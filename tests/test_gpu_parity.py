@@ -419,6 +419,41 @@ def test_conv1d_wino3_ws_is_the_tile_kernel_bit_for_bit(B, L, ld, Cout):
         assert float((y1[..., :L].double().cpu() - ref).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,L,Cout", [(3, 30, 1500, 64), (100, 30, 1500, 64), (2, 30, 1001, 64), (2, 64, 750, 128), (300, 64, 750, 128),
+                                          (3, 64, 501, 128), (1, 30, 2, 64), (2, 30, 10, 64), (2, 64, 5000, 128)])
+def test_conv1d_k4s2_ws_is_the_tile_kernel_bit_for_bit(B, Cin, L, Cout):
+    """The encoder's 4-tap stride-2 layers on 16-byte rows run the weights-stationary kernels (csrc/conv_k4s2_ws.hip: persistent
+    workgroups, a wave's weights in registers, windows by LDS-DMA, one barrier per tile).  Same products in the same order as the tile
+    kernel -- which the same entry point still runs on rows with an odd pitch --, so: equal bit for bit, one tile and many tiles per
+    workgroup, odd and even lengths, NaN in the pitch padding, with / without bias and ReLU, on a side stream; within 1e-5 of float64."""
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(B * 7 + L)
+    Lout = (L - 2) // 2 + 1
+    ld, ldo = (L + 3) & ~3, (Lout + 3) & ~3
+    x = torch.randn(B, Cin, ld, generator=g).to(DEV)
+    x[..., L:] = float("nan")
+    xo = torch.full((B, Cin, L + 1 + (L & 1)), float("nan"), device=DEV)      # odd pitch: not taken by the weights-stationary form
+    xo[..., :L] = x[..., :L]
+    w = (torch.randn(Cout, Cin, 4, generator=g) / math.sqrt(Cin * 4)).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    side = torch.cuda.Stream()
+    for relu, bias in ((1, b), (0, None)):
+        y0 = torch.full((B, Cout, Lout + 1 + (Lout & 1)), -7.0, device=DEV)
+        y1 = torch.full((B, Cout, ldo), -7.0, device=DEV)
+        bp = p(bias) if bias is not None else None
+        assert lib.lbm_conv1d_pitched_f32(p(xo), xo.shape[2], p(w), bp, p(y0), y0.shape[2], B, Cin, L, Cout, 4, 2, 1, relu, None) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            assert lib.lbm_conv1d_pitched_f32(p(x), ld, p(w), bp, p(y1), ldo, B, Cin, L, Cout, 4, 2, 1, relu, _lib.stream_ptr()) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(y0[..., :Lout], y1[..., :Lout])
+        assert not torch.isnan(y1[..., :Lout]).any()
+        ref = torch.nn.functional.conv1d(x[..., :L].double().cpu(), w.double().cpu(), bias.double().cpu() if bias is not None else None,
+                                         stride=2, padding=1)
+        ref = ref.relu() if relu else ref
+        assert float((y1[..., :Lout].double().cpu() - ref).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 30, 1500, 64, 4, 2, 1), (2, 64, 750, 128, 4, 2, 1), (2, 128, 375, 256, 3, 1, 1),
                                                 (2, 256, 375, 256, 1, 1, 0), (2, 12, 130, 40, 3, 1, 1), (1, 20, 9, 7, 1, 1, 0)])
 def test_conv1d_pitched_rows_bitwise_equal_dense(B, Cin, L, Cout, k, s, p):
