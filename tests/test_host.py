@@ -127,6 +127,22 @@ def test_argument_validation_without_launch():
     assert lib.lbm_resample_fft_f32(None, 1000, None, 500, 2, 1000, 3, 7, None, None) < 0
 
 
+def test_library_is_built_from_the_sources_in_the_tree():
+    """A failed rebuild leaves the previous liblbm_hip.so in place and every test keeps passing against it (round 3: an assembler error in
+    a new kernel went unnoticed for three GPU runs).  The library must be newer than every source it is built from, and hold the entry
+    points of the kernels added last (host symbols of csrc/conv_wino_ws.hip and csrc/conv_k4s2_ws.hip)."""
+    from lbm_amd import build as b
+    import shutil
+    if not b.up_to_date() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        b.build()                      # raises if a source no longer compiles
+    assert os.path.exists(b.LIB), "liblbm_hip.so is missing: python -m lbm_amd.build"
+    assert b.up_to_date(), "liblbm_hip.so is older than its sources: python -m lbm_amd.build (and check its exit code)"
+    with open(b.LIB, "rb") as f:
+        blob = f.read()
+    for sym in (b"launch_wino3_ws", b"launch_k4s2_ws", b"wino3_ws_eligible", b"k4s2_ws_eligible"):
+        assert sym in blob, sym
+
+
 def test_lds_dma_kernels_do_not_spill():
     """lbm_amd/build.py records every kernel's register use; the kernels that move data with LDS-DMA must be spill-free
     (build.py NO_SPILL_KERNELS).  No report = no evidence: where hipcc exists the library is rebuilt to produce it, otherwise the
