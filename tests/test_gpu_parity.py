@@ -1326,7 +1326,9 @@ def test_vq_full_size_every_row_is_a_minimum(shipped):
                                             (2 ** 12 - 150, 1, 2, 1),
                                             # resampled padded length not a power of two: chirp-z inverse transform
                                             (30000, 250, 600, 2), (4000, 250, 512, 3), (5000, 256, 500, 1), (3000, 3, 2, 2),
-                                            (100000, 250, 1024, 2), (333, 7, 5, 1), (20, 1, 3, 1)])
+                                            (100000, 250, 1024, 2), (333, 7, 5, 1), (20, 1, 3, 1),
+                                            # an hour of 500 Hz EEG through the chirp-z path (2^21-point padded row, 2^22-point convolution)
+                                            (1_800_000, 250, 600, 1)])
 def test_resample_matches_oracle(T, up, down, rows):
     """raw.resample (preprocessing_unsupervised.py:37): FFT resampling with MNE's auto padding, vs the float64 oracle."""
     rs = np.random.RandomState(T)
