@@ -237,7 +237,11 @@ int lbm_bandpower_f32(const float* psd, const float* freqs, float* out, int64_t 
  * of y at y + (b*Cout + c)*ldy (ldx >= Lin, ldy >= Lout, in floats).  With 16-byte aligned x, y and pitches
  * that are multiples of 4 every global access is a 16-byte one (the layout of the pipeline's activation
  * buffers); the up-to-3 floats of padding at the end of a y row may then be overwritten with unspecified
- * values.  lbm_conv1d_f32 is the dense case ldx = Lin, ldy = Lout. */
+ * values.  lbm_conv1d_f32 is the dense case ldx = Lin, ldy = Lout.
+ * Round 3: the encoder's two 4-tap stride-2 padding-1 layers, (Cin, Cout) = (30, 64) and (64, 128), on such 16-byte rows with
+ * 16-byte aligned weights run as weights-stationary persistent kernels (csrc/conv_k4s2_ws.hip: grid = one workgroup per CU, no limit
+ * on B) -- same products in the same order, same results bit for bit.  Their first call on a device makes two host-side runtime
+ * queries (not capture-safe: warm up once before capturing a graph). */
 int lbm_conv1d_f32(const float* x, const float* w, const float* bias, float* y, int64_t B, int32_t Cin,
                    int32_t Lin, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t relu,
                    lbm_stream_t stream);
@@ -262,7 +266,10 @@ int lbm_conv1d_bf16x6_f32(const float* x, int64_t ldx, const void* tables, const
  * lbm_conv1d_pitched_f32 on that shape (the per-chunk weight loads become four coalesced 16-byte loads per thread: 3-4 % faster on
  * dense random inputs, within noise on the encoder's own post-ReLU activations).
  * lbm_conv1d_wino3_tables_bytes(Cin, Cout): size of the 16-byte aligned device table (0 = unsupported: Cin % 8 != 0 or Cout < 64);
- * lbm_conv1d_wino3_tables_init fills it from w [Cout, Cin, 3].  x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32. */
+ * lbm_conv1d_wino3_tables_init fills it from w [Cout, Cin, 3].  x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32.
+ * Round 3: for Cin = 128, Cout a multiple of 64 and 16-byte rows (the encoder's layer) the call runs a weights-stationary persistent
+ * kernel (csrc/conv_wino_ws.hip: the table's U values as MFMA operands held in registers, 137 KB of LDS per workgroup, one workgroup per
+ * CU): 8-10 % faster, the same results bit for bit.  First call on a device as above (warm up before graph capture). */
 size_t lbm_conv1d_wino3_tables_bytes(int32_t Cin, int32_t Cout);
 int lbm_conv1d_wino3_tables_init(void* tables, const float* w, int32_t Cin, int32_t Cout, lbm_stream_t stream);
 int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tables, const float* bias, float* y, int64_t ldy, int64_t B,
