@@ -34,6 +34,12 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#ifndef LBM_WS_RD
+#define LBM_WS_RD 2
+#endif
+#ifndef LBM_WS_SUB
+#define LBM_WS_SUB 2
+#endif
 constexpr int kThreads = 512;
 constexpr int kCin = 128;
 constexpr int kXW = 140;                       // window samples per input-channel row: positions p0 - 4 .. p0 + 135
@@ -173,10 +179,12 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_ws_kernel(const float* __
         typedef const volatile __attribute__((address_space(3))) f2* lds_vf2;
         const lds_vf4 xq = (lds_vf4)(s_x + buf * kHalfFloats + 4 * h * kXW + 4 * j + 4);
         const lds_vf2 xe = (lds_vf2)(s_x + buf * kHalfFloats + 4 * h * kXW + 4 * j + (KIND == 0 ? 2 : 8));
-        // k-steps are fetched SUB at a time, one sub-step ahead of their MFMAs
-        constexpr int SUB = 4;
-        f4 tq[2][SUB];
-        f2 te[2][SUB];
+        // Three stages in flight: the reads of sub-step u + 2 are requested, the operands of sub-step u + 1 are formed (each in its own
+        // register, between the MFMAs) while the MFMAs of sub-step u are issued.
+        constexpr int SUB = LBM_WS_SUB, NU = 32 / SUB, RD = LBM_WS_RD;   // RD: sub-steps the reads run ahead of the MFMAs
+        f4 tq[RD + 1][SUB];
+        f2 te[RD + 1][SUB];
+        float v[2][SUB][2];
         auto fetch = [&](int u, int set) {
 #pragma unroll
             for (int c = 0; c < SUB; ++c) {
@@ -186,34 +194,36 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_ws_kernel(const float* __
                 if (KIND != 1) te[set][c] = xe[off / 2];
             }
         };
-        fetch(0, 0);
+        auto form = [&](int u, int c) {
+            const f4 q = tq[u % (RD + 1)][c];
+            float a, b;
+            if (KIND == 1) { a = fmaf(sgn, q.x, q.y); b = fmaf(sgn, q.z, q.w); }
+            else if (KIND == 0) { a = te[u % (RD + 1)][c].y - q.y; b = q.y - q.w; }
+            else { a = q.x - q.z; b = q.z - te[u % (RD + 1)][c].x; }
+            asm volatile("" : "+v"(a), "+v"(b));
+            v[u & 1][c][0] = a; v[u & 1][c][1] = b;
+        };
 #pragma unroll
-        for (int u = 0; u < 32 / SUB; ++u) {
-            if (u + 1 < 32 / SUB) fetch(u + 1, (u + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            // the sub-step's A operands first, each in its own register, then its MFMAs back to back (formed one by one in front of
-            // their MFMAs they all went through ONE register: every v_sub then waited for the previous MFMA to have read it)
-            float v[SUB][2];
+        for (int u = 0; u < RD; ++u) fetch(u, u);
 #pragma unroll
-            for (int c = 0; c < SUB; ++c) {
-                const f4 q = tq[u & 1][c];
-                if (KIND == 1) { v[c][0] = fmaf(sgn, q.x, q.y); v[c][1] = fmaf(sgn, q.z, q.w); }
-                else if (KIND == 0) { v[c][0] = te[u & 1][c].y - q.y; v[c][1] = q.y - q.w; }
-                else { v[c][0] = q.x - q.z; v[c][1] = q.z - te[u & 1][c].x; }
-                asm volatile("" : "+v"(v[c][0]), "+v"(v[c][1]));
-            }
+        for (int c = 0; c < SUB; ++c) form(0, c);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (u + RD < NU) fetch(u + RD, (u + RD) % (RD + 1));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < SUB; ++c) {
                 const int tt = u * SUB + c;
                 if (HALF == 0 && tt == 0) {
                     const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][0], ureg[0], z, 0, 0, 0);
-                    acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][1], ureg[0], z, 0, 0, 0);
+                    acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u & 1][c][0], ureg[0], z, 0, 0, 0);
+                    acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u & 1][c][1], ureg[0], z, 0, 0, 0);
                 } else {
-                    acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][0], ureg[HALF * 32 + tt], acc[P][0], 0, 0, 0);
-                    acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[c][1], ureg[HALF * 32 + tt], acc[P][1], 0, 0, 0);
+                    acc[P][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u & 1][c][0], ureg[HALF * 32 + tt], acc[P][0], 0, 0, 0);
+                    acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u & 1][c][1], ureg[HALF * 32 + tt], acc[P][1], 0, 0, 0);
                 }
+                if (u + 1 < NU) form(u + 1, c);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // side work issued while these MFMAs occupy the pipe (once per four k-steps): window requests, the previous tile's exchange and outputs
             if (((u + 1) * SUB) % 4 == 0) hook(((u + 1) * SUB) / 4 - 1);
