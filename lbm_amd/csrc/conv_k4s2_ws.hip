@@ -7,7 +7,7 @@
 // (tests: test_conv1d_k4s2_ws_is_the_tile_kernel_bit_for_bit).
 //
 // A wave owns 32 output channels and 64 of the tile's output positions for the whole launch: its weights W[32 ch][Cin x 4] are its MFMA B
-// operand in 64 / 128 registers, loaded once.  Workgroups (8 waves = NCG channel groups x NPG position groups = ALL output channels x 64 NPG
+// operand in 64 / 128 registers, loaded once.  Workgroups (NCG channel groups x NPG position groups = 8 waves = ALL output channels x 64 NPG
 // positions, one per CU) are persistent and walk the tiles; per tile only the raw input window moves -- Cin rows x (128 NPG + 8) samples,
 // 61 / 66 KiB -- dropped into LDS by LDS-DMA under the previous tile's MFMA stream (two buffers).  ONE barrier per tile (128 / 256 MFMAs of
 // a wave); no staging registers, no ds_write, no arithmetic on the operands: row r of position sub-tile pm is output position 2 r + pm, so
@@ -18,6 +18,8 @@
 // What it replaces (profiles/r03_experiments.md, stamps of conv_tile_kernel): a tile of the first layer spent 48 % of its time in its
 // prologue and epilogue (one exposed load round trip, the LDS writes, 16 scattered stores per lane with their drain) and 22 % in the
 // chunk loop's staging.
+// (NCG x NPG = 4 waves, two such workgroups per CU with their own barriers, was measured: conv1 2.03 vs 2.08 ms, conv2 3.47 vs 3.44 --
+// independent workgroups do not buy what the lockstep of one was thought to cost; the 8-wave shapes stay.)
 #include <type_traits>
 
 #include "common.h"
@@ -29,11 +31,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kThreads = 512;
 
-template <int CIN, int NCG>
+template <int CIN, int NCG, int NPG>
 struct K4Cfg {
-    static constexpr int NPG = 8 / NCG;                     // position groups of 64
+    static constexpr int NW = NCG * NPG;                    // waves per workgroup: channel groups of 32 x position groups of 64
     static constexpr int TP = 64 * NPG;                     // output positions per tile
     static constexpr int XW = 2 * TP + 8;                   // window samples per input-channel row: samples 2 p0 - 4 .. 2 p0 + 2 TP + 3
     static constexpr int X4 = XW / 4;
@@ -43,7 +44,7 @@ struct K4Cfg {
     static constexpr int QUADS = CIN * X4;
     static constexpr int PIECES = (QUADS + 63) / 64;        // 1 KiB DMA pieces per window
     static constexpr int BUF_FLOATS = PIECES * 256;
-    static constexpr int SLOTS = (PIECES + 7) / 8;          // pieces per wave
+    static constexpr int SLOTS = (PIECES + NW - 1) / NW;    // pieces per wave
     static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_FLOATS * sizeof(float);
     static_assert(CIN >= 8 && LDS_BYTES <= 160 * 1024, "window does not fit");
     static_assert((CIN - 5) * XW * 4 + 64 < 65536, "row offsets should fit the 16-bit immediate of a DS instruction");
@@ -61,12 +62,12 @@ __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_dst) {
 // filler quads behind the last row
 __device__ __align__(16) float g_zero_quad_k4[4];
 
-template <int CIN, int NCG>
-__global__ __launch_bounds__(kThreads) void conv_k4s2_ws_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int CIN, int NCG, int NPG>
+__global__ __launch_bounds__(64 * NCG * NPG) void conv_k4s2_ws_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ y, int ldx, int ldy,
                                                                 int Lin, int Lout, int Cout, int relu, int ptiles, int64_t ntiles) {
-    using Cfg = K4Cfg<CIN, NCG>;
-    constexpr int TP = Cfg::TP, XW = Cfg::XW, X4 = Cfg::X4, NCH = Cfg::NCH, NRS = Cfg::NRS, SLOTS = Cfg::SLOTS;
+    using Cfg = K4Cfg<CIN, NCG, NPG>;
+    constexpr int NW = Cfg::NW, TP = Cfg::TP, XW = Cfg::XW, X4 = Cfg::X4, NCH = Cfg::NCH, NRS = Cfg::NRS, SLOTS = Cfg::SLOTS;
     extern __shared__ __align__(16) float smem[];              // 2 x [CIN rows][XW] (+ filler up to a whole piece)
     const unsigned lds_x = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)smem;
 
@@ -91,17 +92,17 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_ws_kernel(const float* __r
     const float bv = bias != nullptr ? bias[co] : 0.f;
     const float lo = relu ? 0.f : -INFINITY;
 
-    const int npieces = wave < Cfg::PIECES - 8 * (SLOTS - 1) ? SLOTS : SLOTS - 1;
+    const int npieces = wave < Cfg::PIECES - NW * (SLOTS - 1) ? SLOTS : SLOTS - 1;
     // Requests piece k of this wave (window quads 64 (wave + 8 k) ..) of tile (b, pt) into buffer `buf`.  Quads wholly outside [0, Lin)
     // come from g_zero_quad_k4, so only the one quad per row that straddles the row's end needs fixing afterwards.
     auto request = [&](int64_t b, int pt, int buf, int k) {
         if (k >= npieces) return;                               // wave-uniform
-        const int q = 64 * (wave + 8 * k) + lane;
+        const int q = 64 * (wave + NW * k) + lane;
         const int row = q / X4, c4 = q - row * X4;
         const int g = 2 * pt * TP - 4 + 4 * c4;
         const float* src = x + b * (int64_t)CIN * ldx;
         const float* a = (q >= Cfg::QUADS || g < 0 || g >= Lin) ? g_zero_quad_k4 : src + (row * ldx + g);
-        lds_dma16(a, lds_x + (unsigned)(buf * Cfg::BUF_FLOATS + 256 * (wave + 8 * k)) * 4u);
+        lds_dma16(a, lds_x + (unsigned)(buf * Cfg::BUF_FLOATS + 256 * (wave + NW * k)) * 4u);
     };
     auto fix_edges = [&](int pt, int buf) {
         const int ga = 2 * pt * TP - 4;
@@ -109,11 +110,11 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_ws_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
             if (k < npieces) {
-                const int q = 64 * (wave + 8 * k) + lane;
+                const int q = 64 * (wave + NW * k) + lane;
                 const int row = q / X4, c4 = q - row * X4;
                 const int g = ga + 4 * c4;
                 if (q < Cfg::QUADS && g < Lin && g + 4 > Lin) {
-                    float* d = smem + buf * Cfg::BUF_FLOATS + 256 * (wave + 8 * k) + 4 * lane;
+                    float* d = smem + buf * Cfg::BUF_FLOATS + 256 * (wave + NW * k) + 4 * lane;
 #pragma unroll
                     for (int e = 1; e < 4; ++e)
                         if (g + e >= Lin) d[e] = 0.f;
@@ -228,10 +229,10 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_ws_kernel(const float* __r
 int g_cus[64];
 bool g_attr[64][2];
 
-template <int CIN, int NCG>
+template <int CIN, int NCG, int NPG>
 int launch(int which, const float* x, const float* w, const float* bias, float* y, int64_t B, int Lin, int64_t ldx, int Lout, int64_t ldy,
            int relu, hipStream_t st) {
-    using Cfg = K4Cfg<CIN, NCG>;
+    using Cfg = K4Cfg<CIN, NCG, NPG>;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return lbm::fail(LBM_ELAUNCH, "lbm_conv1d_f32: hipGetDevice failed");
     if (g_cus[dev] == 0) {
@@ -239,7 +240,7 @@ int launch(int which, const float* x, const float* w, const float* bias, float* 
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         g_cus[dev] = n;
     }
-    auto k = conv_k4s2_ws_kernel<CIN, NCG>;
+    auto k = conv_k4s2_ws_kernel<CIN, NCG, NPG>;
     if (!g_attr[dev][which]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
         if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_conv1d_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -247,8 +248,9 @@ int launch(int which, const float* x, const float* w, const float* bias, float* 
     }
     const int ptiles = (Lout + Cfg::TP - 1) / Cfg::TP;
     const int64_t ntiles = B * ptiles;
-    const int grid = (int)(ntiles < g_cus[dev] ? ntiles : g_cus[dev]);   // one workgroup per CU (LDS), each walks ntiles / grid tiles
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kThreads), Cfg::LDS_BYTES, st, x, w, bias, y, (int)ldx, (int)ldy, Lin, Lout, 32 * NCG, relu,
+    const int64_t slots = (int64_t)g_cus[dev] * (Cfg::NW <= 4 ? 2 : 1);  // resident workgroups: one 8-wave or two 4-wave per CU (LDS, registers)
+    const int grid = (int)(ntiles < slots ? ntiles : slots);            // each walks ntiles / grid tiles
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(64 * Cfg::NW), Cfg::LDS_BYTES, st, x, w, bias, y, (int)ldx, (int)ldy, Lin, Lout, 32 * NCG, relu,
                        ptiles, ntiles);
     return lbm::check_launch("lbm_conv1d_f32");
 }
@@ -264,8 +266,8 @@ bool k4s2_ws_eligible(const float* x, int64_t ldx, const float* w, const float* 
 
 int launch_k4s2_ws(const float* x, const float* w, const float* bias, float* y, int64_t B, int Cin, int Lin, int64_t ldx, int Cout, int Lout,
                    int64_t ldy, int relu, hipStream_t st) {
-    if (Cin == 30) return launch<30, 2>(0, x, w, bias, y, B, Lin, ldx, Lout, ldy, relu, st);
-    return launch<64, 4>(1, x, w, bias, y, B, Lin, ldx, Lout, ldy, relu, st);
+    if (Cin == 30) return launch<30, 2, 4>(0, x, w, bias, y, B, Lin, ldx, Lout, ldy, relu, st);
+    return launch<64, 4, 2>(1, x, w, bias, y, B, Lin, ldx, Lout, ldy, relu, st);
 }
 
 }  // namespace lbm
