@@ -582,10 +582,14 @@ __global__ __launch_bounds__(64 * TS) __attribute__((amdgpu_waves_per_eu((TS == 
             auto fast = [&](const Ld& o, const f32x2 w, const float4 bs) {
                 const f32x2 a = w * (((o.da - b0v) + (o.db - b0v)) - m2v);  // {a1, a2}
                 const f32x2 b = w * (o.da - o.db);          // {b1, b2}
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x + a.y, bs.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x - b.y, bs.y, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x - a.y, bs.z, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x + b.y, bs.w, acc[3], 0, 0, 0);
+                // the four A operands first, each in its own register (formed one by one in front of their MFMAs they all went through
+                // ONE register, and every v_add then waited for the previous MFMA to have read it: round 3, conv_wino_ws.hip)
+                float o0 = a.x + a.y, o1 = b.x - b.y, o2 = a.x - a.y, o3 = b.x + b.y;
+                asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o0, bs.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o1, bs.y, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(o2, bs.z, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(o3, bs.w, acc[3], 0, 0, 0);
             };
             // st = 0: t = 0 on wave 0 (there d[N - n] of lane n = 0 would be another segment's sample: never read it)
             if (t_lo == 0) generic(0, breg[0]);             // uniform
