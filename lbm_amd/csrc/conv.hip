@@ -437,7 +437,10 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_kernel(const float* __res
 #pragma unroll
         for (int s = slo; s < shi; ++s) {
             const float d0 = xp[s * XW], d1 = xp[s * XW + 1], d2 = xp[s * XW + 2], d3 = xp[s * XW + 3];
-            const float v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+            // (each V in its own register, pinned: formed one by one in front of their MFMAs they went through ONE register and every
+            // v_sub waited for the previous MFMA to have read it -- tools/asm_war_scan.py, round 3: 36 of a chunk's 64 MFMAs)
+            float v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+            asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
