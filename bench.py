@@ -44,16 +44,20 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 KERNEL_OF_STAGE = {"fir": "fir_fft_kernel", "affine_post": "affine_post_kernel<1,6,true>", "affine": "affine_kernel", "post": "post_kernel", "welch": "welch_team_kernel<2,1>",
-                   "bandpower": "bandpower_kernel", "conv1": "conv_k4s2_ws_kernel<30,2>", "conv2": "conv_k4s2_ws_kernel<64,4>",
+                   "bandpower": "bandpower_kernel", "conv1": "conv_k4s2_wino_ws_kernel<32>", "conv2": "conv_k4s2_wino_ws_kernel<64>",
                    "conv3": "conv_wino3_ws_kernel", "conv4": "conv_tile_kernel<1,1,256>", "vq": "vq_argmin_dma_kernel"}
+KERNEL_OF_K4S2_DIRECT = {"conv1": "conv_k4s2_ws_kernel<30,2>", "conv2": "conv_k4s2_ws_kernel<64,4>"}
 KERNEL_OF_VQ = {"fp32": "vq_argmin_dma_kernel", "bf16x6": "vq_bf16x6_kernel", "screen": "vq_screen_pipe_kernel<1> (+ vq_argmin_kernel<256,1,true> on the unsettled rows)"}
 
 
-def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, vq_method="fp32"):
+def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, vq_method="fp32", conv_k4s2="wino"):
     """Algorithmic flops / compulsory HBM bytes per launch of each stage over E epochs (SURVEY.md 8d figures).  `flops` is the
     reference's arithmetic; where a kernel executes something else (Winograd: 2/3 of the products; the screened quantizer: three
     bf16 piece products per fp32 product on the bf16 matrix cores) `exec_flops` / `peak` say what ran and against which peak."""
     ep = C * T * 4
+    # the 4-tap stride-2 layers as two 2-tap phases in F(3,2): 4 products per 3 outputs and phase instead of 6 (where rows are 16-byte
+    # pitched and Cin <= 64: what EpochPipeline checks)
+    k4 = (lambda fl, ldx, ldy, cin: {"exec_flops": fl * 2.0 / 3.0} if conv_k4s2 == "wino" and ldx % 4 == 0 and cin <= 64 else {})
     fft_flops = 2 * 5.0 * fft_n * np.log2(fft_n) + 6.0 * fft_n       # forward + inverse complex FFT + spectrum product, per row
     return {
         "fir": dict(flops=fft_flops * C * E, direct_flops=2.0 * ntaps * C * T * E, bytes=2.0 * ep * E, bound="hbm"),
@@ -63,8 +67,9 @@ def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, 
         "affine_post": dict(flops=(2.0 * C * C + 8.0 * C) * T * E, bytes=(3.0 if emit_cleaned else 2.0) * ep * E, bound="hbm"),
         "welch": dict(flops=2.0e6 * E * (C * T / 45000.0), bytes=(ep + C * F * 4) * E, bound="hbm"),
         "bandpower": dict(flops=0.0, bytes=(C * F * 4 + 24) * E, bound="hbm"),
-        "conv1": dict(flops=2.0 * 64 * C * 4 * L1 * E, bytes=(ep + 64 * L1 * 4) * E, bound="mfma"),
-        "conv2": dict(flops=2.0 * 128 * 64 * 4 * S * E, bytes=(64 * L1 * 4 + 128 * S * 4) * E, bound="mfma"),
+        "conv1": dict(flops=2.0 * 64 * C * 4 * L1 * E, bytes=(ep + 64 * L1 * 4) * E, bound="mfma", **k4(2.0 * 64 * C * 4 * L1 * E, T, 0, C)),
+        "conv2": dict(flops=2.0 * 128 * 64 * 4 * S * E, bytes=(64 * L1 * 4 + 128 * S * 4) * E, bound="mfma",
+                      **k4(2.0 * 128 * 64 * 4 * S * E, 0, 0, 64)),
         "conv3": dict(flops=2.0 * 256 * 128 * 3 * S * E, exec_flops=2.0 * 256 * 128 * 2 * S * E, bytes=(128 * S * 4 + 256 * S * 4) * E,
                       bound="mfma"),
         "conv4": dict(flops=2.0 * D * 256 * S * E, bytes=(256 * S * 4 + D * S * 4) * E, bound="mfma"),
@@ -305,6 +310,9 @@ def parse_args(argv=None):
                          "(outside the timed region); 0 = all of them")
     ap.add_argument("--conv", choices=["fp32", "bf16x6"], default="fp32",
                     help="256-channel encoder layers: fp32 MFMA kernels (default) or the three-bf16-piece implicit GEMM")
+    ap.add_argument("--conv-k4s2", choices=["wino", "direct"], default="wino",
+                    help="the two 4-tap stride-2 encoder layers: two 2-tap phases in the minimal form F(3,2) (default; 2/3 of the "
+                         "products, fp32 MFMA, same accuracy vs float64) or the direct form")
     ap.add_argument("--no-fold-proj", dest="fold_proj", action="store_false",
                     help="run the encoder's last 1x1 convolution as its own GEMM and quantise its output z (the layer chain as "
                          "training/model.py:169-177 writes it).  Default: the layer is folded into the codebook "
@@ -524,7 +532,7 @@ def run_rank(args):
     nb = int(round(0.5 * fs)) + 1
     cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb,
                                  fold_projection=args.fold_proj, vq_method=args.vq, conv_method=args.conv,
-                                 emit_cleaned=args.emit_cleaned)
+                                 conv_k4s2=args.conv_k4s2, emit_cleaned=args.emit_cleaned)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -543,7 +551,7 @@ def run_rank(args):
     # room left beside the resident input: allocator slack, RCCL's buffers and (N > 1) the flattened receive buffers torch
     # stages one group of each array through before it scatters them to the [w, lo:hi] slices
     reserve = 6 << 30
-    run_variants = rank == 0 and args.shape == "S" and args.fold_proj and args.vq == "screen" and args.conv == "fp32"
+    run_variants = rank == 0 and args.shape == "S" and args.fold_proj and args.vq == "screen" and args.conv == "fp32" and args.conv_k4s2 == "wino"
     z_var = None
     if run_variants:      # the unfolded variants write z: take that buffer before the resident input claims the rest of the HBM
         z_var = torch.empty((chunk, D, pipe.P2), dtype=torch.float32, device=dev)
@@ -663,7 +671,8 @@ def run_rank(args):
             acc.setdefault(name, []).append(s_.elapsed_time(e_))
         pipe.stage_events = None
         fft_n = 2048 if args.shape == "S" else 3 * 4096
-        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned, vq_method=args.vq)
+        model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned, vq_method=args.vq,
+                            conv_k4s2=args.conv_k4s2)
         stages = stage_report(acc, model)
 
     # the screened quantizer against the fp32 search it stands for: EVERY token of one whole step (all chunks of the job, walked as
@@ -671,7 +680,7 @@ def run_rank(args):
     screen_check = None
     if rank == 0 and args.vq == "screen":
         kw = dict(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, conv_method=args.conv,
-                  fold_projection=args.fold_proj)
+                  conv_k4s2=args.conv_k4s2, fold_projection=args.fold_proj)
         ref_pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(vq_method="fp32", **kw), taps, A, b, weights, codebook, device=dev)
         ref_pipe._buf, ref_pipe._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z too, if unfolded)
         ref_pipe._buf["tokens"] = torch.empty_like(pipe._buf["tokens"])
@@ -700,13 +709,16 @@ def run_rank(args):
     variants = {}
     if run_variants:
         base_ms = sum(v["ms"] for v in stages.values())
-        for name, kw in (("fp32_search_of_every_row", dict(vq_method="fp32", fold_projection=True)),
+        for name, kw in (("default_timed_the_same_way", dict(vq_method="screen", fold_projection=True)),   # the first chunk three times, no exchange
+                         ("conv_k4s2_direct", dict(vq_method="screen", fold_projection=True, conv_k4s2="direct")),
+                         ("fp32_search_of_every_row", dict(vq_method="fp32", fold_projection=True)),
                          ("fp32_unfolded_projection", dict(vq_method="fp32", fold_projection=False)),
                          ("vq_bf16x6", dict(vq_method="bf16x6")),
                          ("vq_bf16x6+conv_bf16x6", dict(vq_method="bf16x6", conv_method="bf16x6")),
                          ("vq_bf16x6+fold_projection", dict(vq_method="bf16x6", fold_projection=True)),
                          ("vq_bf16x6+conv_bf16x6+fold_projection", dict(vq_method="bf16x6", conv_method="bf16x6", fold_projection=True))):
-            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, **kw)
+            vcfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned,
+                                          **{"conv_k4s2": args.conv_k4s2, **kw})
             vp = lbm_amd.EpochPipeline(vcfg, taps, A, b, weights, codebook, device=dev)
             vp._buf, vp._cap = {**pipe._buf}, pipe._cap          # share the stage buffers
             if not vcfg.fold_projection and "z" not in vp._buf:  # the unfolded variants write z (6.3 GB per 16384-epoch chunk)
@@ -735,7 +747,10 @@ def run_rank(args):
         key, peak, unit = ("tflops", PEAK_FP32_TFLOPS, "TFLOP/s") if m["bound"] == "mfma" else ("gbs", PEAK_HBM_GBS, "GB/s")
         if m["bound"] == "mfma" and "peak" in m:      # ran on another unit than the fp32 matrix cores: executed flops against its peak
             key, peak = "executed_tflops", m["peak"]
-        roof = {"kernel": KERNEL_OF_VQ[args.vq] if dom == "vq" else KERNEL_OF_STAGE.get(dom, dom), "bound": m["bound"],
+        kname = KERNEL_OF_VQ[args.vq] if dom == "vq" else KERNEL_OF_STAGE.get(dom, dom)
+        if args.conv_k4s2 == "direct":
+            kname = KERNEL_OF_K4S2_DIRECT.get(dom, kname)
+        roof = {"kernel": kname, "bound": m["bound"],
                 "achieved": stages[dom][key], "peak": peak, "unit": unit,
                 "frac": round(stages[dom][key] / peak, 4), "executed_frac": stages[dom].get("executed_frac"), "traffic": traffic,
                 "traffic_source": "stored counter run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this launch, "
@@ -769,7 +784,7 @@ def run_rank(args):
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "conv_k4s2": args.conv_k4s2, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
                        "collectives": coll, "backend": args.backend if xch is not None else None},
             "roofline": roof,

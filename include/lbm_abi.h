@@ -275,6 +275,19 @@ int lbm_conv1d_wino3_tables_init(void* tables, const float* w, int32_t Cin, int3
 int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tables, const float* bias, float* y, int64_t ldy, int64_t B,
                          int32_t Cin, int32_t Lin, int32_t Cout, int32_t relu, lbm_stream_t stream);
 
+/* The 4-tap, stride-2, padding-1 layers (the encoder's first two convolutions, training/model.py:169-172) in a form with 2/3 of the
+ * products (round 3): y[p] = (w1 x[2p] + w3 x[2p+2]) + (w0 x[2p-1] + w2 x[2p+1]) is two 2-tap stride-1 correlations, one over the even
+ * and one over the odd input samples, and each is computed three outputs at a time by the minimal-filtering (Winograd) form F(3,2):
+ * 4 products per 3 outputs and phase instead of 6, the transforms exact or one rounding each (csrc/conv_k4s2_wino_ws.hip:
+ * weights-stationary persistent kernel, 117 KB of LDS per workgroup, one workgroup per CU).  The results differ from
+ * lbm_conv1d_pitched_f32's by rounding only (both within ~1e-6 of a float64 convolution at the encoder's scales) and are NOT
+ * bit-identical to it.  Supported (lbm_conv1d_k4s2_wino_supported != 0): 1 <= Cin <= 64, Cout a multiple of 64; rows must be 16-byte
+ * pitched (ldx, ldy multiples of 4) and x, w, y 16-byte aligned, otherwise LBM_EUNSUPPORTED (callers then use lbm_conv1d_pitched_f32).
+ * w is [Cout, Cin, 4]; x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32; Lout = (Lin - 2) / 2 + 1. */
+int lbm_conv1d_k4s2_wino_supported(int32_t Cin, int32_t Cout);
+int lbm_conv1d_k4s2_wino_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t B,
+                             int32_t Cin, int32_t Lin, int32_t Cout, int32_t relu, lbm_stream_t stream);
+
 /* ---- a12 / a13: codebook distance + argmin ----------------------------------------------------------
  * Replaces VectorQuantizerEMA.get_code_indices, training/model.py:152-158 (same math in forward :90-95):
  * d[n,k] = (sum(x_n^2) + sum(e_k^2)) - 2 * (x_n . e_k) in fp32, idx[n] = first k attaining the minimum.

@@ -42,8 +42,10 @@ def up_to_date() -> bool:
 # timing-dependent fault of THAT kernel's LDS-read / MFMA stage, which the spill-free build shows as well once 16 idle cycles follow each
 # MFMA.  The kernels in the tree today keep their outputs bit for bit under the same perturbations: tools/perturb_build.py +
 # tools/timing_robustness.py.)
-NO_SPILL_FILES = {"vq.hip", "vq_bf16.hip", "vq_screen.hip", "conv_bf16.hip", "welch.hip"}
-NO_SPILL_KERNELS = ("vq_argmin_dma_kernel", "vq_bf16x6_kernel", "vq_screen_kernel", "vq_screen_pipe_kernel", "conv_bf16x6_kernel", "welch_team_kernel")
+NO_SPILL_FILES = {"vq.hip", "vq_bf16.hip", "vq_screen.hip", "conv_bf16.hip", "welch.hip", "conv_wino_ws.hip", "conv_k4s2_ws.hip",
+                  "conv_k4s2_wino_ws.hip"}
+NO_SPILL_KERNELS = ("vq_argmin_dma_kernel", "vq_bf16x6_kernel", "vq_screen_kernel", "vq_screen_pipe_kernel", "conv_bf16x6_kernel", "welch_team_kernel",
+                    "conv_wino3_ws_kernel", "conv_k4s2_ws_kernel", "conv_k4s2_wino_ws_kernel")
 
 
 def _resources(remarks: str) -> dict:

@@ -718,3 +718,22 @@ extern "C" int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tab
         return lbm::launch_wino3_ws(x, static_cast<const float*>(tables), bias, y, B, Lin, ldx, Cout, ldy, relu, lbm::as_stream(stream));
     return launch_wino3(x, static_cast<const float*>(tables), bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, relu, lbm::as_stream(stream), true);
 }
+
+// nn.Conv1d(kernel 4, stride 2, padding 1) as two 2-tap phases in the minimal form F(3,2): conv_k4s2_wino_ws.hip
+extern "C" int lbm_conv1d_k4s2_wino_supported(int32_t Cin, int32_t Cout) { return Cin >= 1 && Cin <= 64 && Cout >= 64 && Cout % 64 == 0; }
+
+extern "C" int lbm_conv1d_k4s2_wino_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t B,
+                                        int32_t Cin, int32_t Lin, int32_t Cout, int32_t relu, lbm_stream_t stream) {
+    LBM_REQUIRE(B >= 0 && Lin >= 2, LBM_EINVAL, "lbm_conv1d_k4s2_wino_f32: bad sizes (B=%lld, Lin=%d)", (long long)B, Lin);
+    LBM_REQUIRE(lbm_conv1d_k4s2_wino_supported(Cin, Cout), LBM_EUNSUPPORTED,
+                "lbm_conv1d_k4s2_wino_f32: Cin=%d must be 1..64 and Cout=%d a multiple of 64 (use lbm_conv1d_pitched_f32)", Cin, Cout);
+    const int Lout = (Lin + 2 - 4) / 2 + 1;
+    LBM_REQUIRE(ldx >= Lin && ldy >= Lout, LBM_EINVAL, "lbm_conv1d_k4s2_wino_f32: row pitch smaller than the row");
+    LBM_REQUIRE((int64_t)Cin * ldx <= 0x7fffffffLL && (int64_t)Cout * ldy <= 0x7fffffffLL, LBM_EUNSUPPORTED,
+                "lbm_conv1d_k4s2_wino_f32: one epoch exceeds 2^31 elements");
+    if (B == 0) return LBM_OK;
+    LBM_REQUIRE(x && w && y, LBM_EINVAL, "lbm_conv1d_k4s2_wino_f32: NULL pointer");
+    LBM_REQUIRE(lbm::k4s2_wino_eligible(x, ldx, w, y, ldy, Cin, Cout, Lin), LBM_EUNSUPPORTED,
+                "lbm_conv1d_k4s2_wino_f32: rows must be 16-byte pitched (ldx, ldy multiples of 4) and x, w, y 16-byte aligned");
+    return lbm::launch_k4s2_wino(x, w, bias, y, B, Cin, Lin, ldx, Cout, Lout, ldy, relu, lbm::as_stream(stream));
+}

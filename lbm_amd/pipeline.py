@@ -46,6 +46,9 @@ class PipelineConfig:
                                        # pieces on the bf16 MFMA (same accuracy vs float64, ~1.6x faster; near-tie rule)
     conv_method: str = "fp32"          # 'bf16x6': the encoder's 256-channel layers (3rd conv, 1x1 projection) on the bf16 MFMA
                                        # with three-piece operands (conv_bf16.hip; same accuracy vs float64 as the fp32 chain)
+    conv_k4s2: str = "wino"            # the two 4-tap stride-2 layers: 'wino' = two 2-tap phases in the minimal form F(3,2)
+                                       # (lbm_conv1d_k4s2_wino_f32: 2/3 of the products, same accuracy vs float64 as the direct
+                                       # chain, not bit-identical to it) wherever rows are 16-byte pitched; 'direct' = lbm_conv1d_pitched_f32
     fuse_post: bool = True             # ICA affine + baseline / reject / z-score in one kernel (lbm_affine_post_f32) and Welch on the
                                        # z-scored epochs with the per-row scale (lbm_welch_scaled_f32): 900 000 instead of
                                        # 1 260 000 B of HBM traffic per 30x1500 epoch in the DSP front; False = the separate kernels
@@ -100,6 +103,8 @@ class EpochPipeline:
                 self.vq_tab = vq_split_tables(self.cb_fold if cfg.fold_projection else self.codebook)
             if cfg.conv_method not in ("fp32", "bf16x6"):
                 raise ValueError(f"conv_method {cfg.conv_method!r}")
+            if cfg.conv_k4s2 not in ("wino", "direct"):
+                raise ValueError(f"conv_k4s2 {cfg.conv_k4s2!r}")
             self.conv_tab = {}
             if cfg.conv_method == "bf16x6":
                 from .quantizer import conv_split_tables
@@ -241,6 +246,10 @@ class EpochPipeline:
                 if i == 4 and tab is None and self.wino_tab is not None and (ks, s_, pd) == (3, 1, 1):
                     _lib.check(lib.lbm_conv1d_wino3_f32(p(xi), ldx, p(self.wino_tab), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin,
                                                         cout, relu, st), "conv(wino3)")
+                elif (tab is None and c.conv_k4s2 == "wino" and (ks, s_, pd) == (4, 2, 1) and ldx % 4 == 0 and ldy % 4 == 0 and
+                      lib.lbm_conv1d_k4s2_wino_supported(cin, cout)):
+                    _lib.check(lib.lbm_conv1d_k4s2_wino_f32(p(xi), ldx, p(e[f"encoder.{i}.weight"]), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E,
+                                                            cin, lin, cout, relu, st), "conv(k4s2 wino)")
                 elif tab is not None:
                     _lib.check(lib.lbm_conv1d_bf16x6_f32(p(xi), ldx, p(tab), p(e[f"encoder.{i}.bias"]), p(yo), ldy, E, cin, lin, cout,
                                                          ks, s_, pd, relu, st), "conv(bf16x6)")

@@ -454,6 +454,58 @@ def test_conv1d_k4s2_ws_is_the_tile_kernel_bit_for_bit(B, Cin, L, Cout):
         assert float((y1[..., :Lout].double().cpu() - ref).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,Cin,L,Cout", [(3, 64, 750, 128), (300, 64, 750, 128), (2, 30, 1500, 64), (100, 30, 1500, 64), (2, 64, 1001, 64),
+                                          (1, 30, 39, 64), (4, 17, 200, 192), (2, 64, 2, 128), (3, 64, 5, 64), (2, 48, 3000, 128),
+                                          (1, 64, 383, 128), (1, 64, 385, 128), (2, 1, 64, 64)])
+def test_conv1d_k4s2_wino_matches_float64(B, Cin, L, Cout):
+    """lbm_conv1d_k4s2_wino_f32 (csrc/conv_k4s2_wino_ws.hip): the 4-tap stride-2 layers (training/model.py:169-172) as two 2-tap phases
+    in the minimal form F(3,2).  Not the direct kernels' bits (the transforms round differently), so the bar is float64: within 4e-6 of
+    the output scale -- the direct kernel's own distance on the same inputs is asserted beside it, and the two agree to 5e-6 -- over one
+    tile and many tiles per workgroup, odd and even lengths, rows that end inside a quad, fewer than 32 / 64 input channels, NaN in the
+    pitch padding of x, with / without bias and ReLU, on a side stream; columns past a row's last quad are never written."""
+    lib, p = _lib.load(), _lib.ptr
+    g = torch.Generator().manual_seed(B * 11 + L)
+    Lout = (L - 2) // 2 + 1
+    ld, ldo = (L + 3) & ~3, ((Lout + 3) & ~3) + 4
+    x = torch.randn(B, Cin, ld, generator=g).to(DEV)
+    x[..., L:] = float("nan")
+    w = (torch.randn(Cout, Cin, 4, generator=g) / math.sqrt(Cin * 4)).to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    assert lib.lbm_conv1d_k4s2_wino_supported(Cin, Cout) == 1
+    side = torch.cuda.Stream()
+    for relu, bias in ((1, b), (0, None)):
+        y0 = torch.full((B, Cout, ldo), -7.0, device=DEV)
+        y1 = torch.full((B, Cout, ldo), -7.0, device=DEV)
+        bp = p(bias) if bias is not None else None
+        assert lib.lbm_conv1d_pitched_f32(p(x), ld, p(w), bp, p(y0), ldo, B, Cin, L, Cout, 4, 2, 1, relu, None) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            assert lib.lbm_conv1d_k4s2_wino_f32(p(x), ld, p(w), bp, p(y1), ldo, B, Cin, L, Cout, relu, _lib.stream_ptr()) == 0, _lib.last_error()
+        torch.cuda.synchronize()
+        assert not torch.isnan(y1[..., :Lout]).any()
+        assert bool((y1[..., (Lout + 3) // 4 * 4:] == -7.0).all())
+        ref = torch.nn.functional.conv1d(x[..., :L].double().cpu(), w.double().cpu(), bias.double().cpu() if bias is not None else None,
+                                         stride=2, padding=1)
+        ref = ref.relu() if relu else ref
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((y1[..., :Lout].double().cpu() - ref).abs().max()) <= 4e-6 * scale
+        assert float((y0[..., :Lout].double().cpu() - ref).abs().max()) <= 6e-6 * scale
+        assert float((y1[..., :Lout] - y0[..., :Lout]).abs().max()) <= 5e-6 * scale
+
+
+def test_conv1d_k4s2_wino_rejects_what_it_does_not_take():
+    lib, p = _lib.load(), _lib.ptr
+    assert lib.lbm_conv1d_k4s2_wino_supported(65, 128) == 0 and lib.lbm_conv1d_k4s2_wino_supported(64, 96) == 0
+    x = torch.zeros(2, 64, 752, device=DEV)
+    w = torch.zeros(128, 64, 4, device=DEV)
+    y = torch.zeros(2, 128, 376, device=DEV)
+    assert lib.lbm_conv1d_k4s2_wino_f32(p(x), 751, p(w), None, p(y), 376, 2, 64, 750, 128, 1, None) == -2      # odd pitch
+    assert lib.lbm_conv1d_k4s2_wino_f32(p(x), 752, p(w), None, p(y), 376, 2, 65, 750, 128, 1, None) == -2      # Cin
+    assert lib.lbm_conv1d_k4s2_wino_f32(p(x), 752, p(w), None, p(y), 372, 2, 64, 750, 128, 1, None) == -1            # ldy < Lout
+    assert lib.lbm_conv1d_k4s2_wino_f32(p(x), 752, None, None, p(y), 376, 2, 64, 750, 128, 1, None) == -1            # NULL
+    assert lib.lbm_conv1d_k4s2_wino_f32(p(x), 752, p(w), None, p(y), 376, 0, 64, 750, 128, 1, None) == 0                      # B = 0
+
+
 @pytest.mark.parametrize("B,Cin,L,Cout,k,s,p", [(3, 30, 1500, 64, 4, 2, 1), (2, 64, 750, 128, 4, 2, 1), (2, 128, 375, 256, 3, 1, 1),
                                                 (2, 256, 375, 256, 1, 1, 0), (2, 12, 130, 40, 3, 1, 1), (1, 20, 9, 7, 1, 1, 0)])
 def test_conv1d_pitched_rows_bitwise_equal_dense(B, Cin, L, Cout, k, s, p):
@@ -1091,6 +1143,28 @@ def test_pipeline_folded_projection_tokens(shipped, vq_golden, codebook, vq_meth
         tk = vq_argmin(h3, cbf, eef, channel_major=True, no_xnorm=True).view(xs.shape[0], -1).cpu().numpy()
         zg = np.transpose(vq_golden["z_S"], (0, 2, 1)).reshape(-1, 256)
         assert orc.vq_near_tie_ok(zg, cb, tk.reshape(-1), vq_golden["tokens_S"].reshape(-1)).all()
+
+
+def test_pipeline_k4s2_wino_tokens_are_the_direct_layers_tokens(shipped):
+    """PipelineConfig.conv_k4s2: 'wino' (default; the first two encoder layers through lbm_conv1d_k4s2_wino_f32) against 'direct'
+    (lbm_conv1d_pitched_f32): z within 2e-5 of its scale, tokens equal except documented near-ties of the direct path's own z, PSD /
+    band power / keep mask untouched (bit for bit: the DSP front does not change)."""
+    cb = shipped["vq_layer.embedding.weight"]
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    mk = lambda how: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(conv_k4s2=how), taps, A, b, shipped, cb)  # noqa: E731
+    x = (synth_epochs(96, 30, 1500, seed=22) * 2.0).to(DEV)
+    ref = {k: v.clone() for k, v in mk("direct").run(x).items()}
+    out = mk("wino").run(x)
+    for k in ("psd", "bandpower", "keep", "standardized"):
+        assert torch.equal(out[k], ref[k]), k
+    zr = ref["z"].permute(0, 2, 1).reshape(-1, 256).cpu().numpy()
+    assert float((out["z"] - ref["z"]).abs().max()) <= 2e-5 * max(1.0, float(ref["z"].abs().max()))
+    tok, tok_ref = out["tokens"].cpu().numpy(), ref["tokens"].cpu().numpy()
+    assert (tok == tok_ref).mean() >= 0.999
+    assert orc.vq_near_tie_ok(zr, cb, tok.reshape(-1), tok_ref.reshape(-1)).all()
+    with pytest.raises(ValueError):
+        mk("fast")
 
 
 def test_pipeline_without_cleaned_output(shipped):

@@ -139,7 +139,7 @@ def test_library_is_built_from_the_sources_in_the_tree():
     assert b.up_to_date(), "liblbm_hip.so is older than its sources: python -m lbm_amd.build (and check its exit code)"
     with open(b.LIB, "rb") as f:
         blob = f.read()
-    for sym in (b"launch_wino3_ws", b"launch_k4s2_ws", b"wino3_ws_eligible", b"k4s2_ws_eligible"):
+    for sym in (b"launch_wino3_ws", b"launch_k4s2_ws", b"wino3_ws_eligible", b"k4s2_ws_eligible", b"launch_k4s2_wino", b"k4s2_wino_eligible"):
         assert sym in blob, sym
 
 
@@ -188,6 +188,19 @@ def test_vq_screen_workspace_and_arguments():
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 0, 0, None, None, None, None, None, None, 10, 250, 512, None) == -2
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 7, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
+
+
+def test_conv_k4s2_wino_arguments():
+    """lbm_conv1d_k4s2_wino_f32 argument checks that need no GPU (include/lbm_abi.h)."""
+    lib = _lib.load()
+    assert lib.lbm_conv1d_k4s2_wino_supported(64, 128) == 1 and lib.lbm_conv1d_k4s2_wino_supported(30, 64) == 1
+    assert lib.lbm_conv1d_k4s2_wino_supported(65, 128) == 0 and lib.lbm_conv1d_k4s2_wino_supported(64, 100) == 0
+    assert lib.lbm_conv1d_k4s2_wino_supported(0, 64) == 0 and lib.lbm_conv1d_k4s2_wino_supported(64, 0) == 0
+    assert lib.lbm_conv1d_k4s2_wino_f32(None, 752, None, None, None, 376, 0, 64, 750, 128, 1, None) == 0       # B == 0
+    assert lib.lbm_conv1d_k4s2_wino_f32(None, 752, None, None, None, 376, 4, 64, 750, 128, 1, None) == -1      # NULL pointers
+    assert lib.lbm_conv1d_k4s2_wino_f32(None, 752, None, None, None, 376, 4, 128, 750, 128, 1, None) == -2     # Cin > 64
+    assert lib.lbm_conv1d_k4s2_wino_f32(None, 700, None, None, None, 376, 4, 64, 750, 128, 1, None) == -1      # pitch < row
+    assert lib.lbm_conv1d_k4s2_wino_f32(None, 752, None, None, None, 376, 4, 64, 1, 128, 1, None) == -1        # Lin < 2
 
 
 def test_conv_wino3_table_sizes_and_arguments():
