@@ -38,15 +38,20 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 512;
 constexpr int kXW = 392;                        // window samples per input row: x[384 pt - 4 .. 384 pt + 387]
 constexpr int kX4 = kXW / 4;                    // 98 quads
-constexpr int kPhRows = 16;                     // input rows per phase
-constexpr int kPhQuads = kPhRows * kX4;         // 1 568
-constexpr int kPieces = (kPhQuads + 63) / 64;   // 25 DMA pieces of 1 KiB (the last one half used)
-constexpr int kBufFloats = kPieces * 256;       // 25 600 B per buffer
-constexpr int kSlots = (kPieces + 7) / 8;       // pieces per wave (wave 0 owns four, the others three)
-constexpr int kExFloats = 8 * 2 * 16 * 64;      // [wave][position sub-tile][register][lane]
-constexpr size_t kLdsBytes = (2 * (size_t)kBufFloats + kExFloats) * sizeof(float);   // 116 736
+constexpr int kExFloats = 8 * 2 * 12 * 64;      // [wave][position sub-tile][3 register quads][lane]: a wave keeps the quad it outputs itself
 
-static_assert(kSlots == 4, "the request schedule in the tile walk names four pieces per wave");
+template <int CINP>
+struct Geo {                                    // a tile's window is staged in two phases of CINP / 2 input rows
+    static constexpr int kPhRows = CINP / 2;                  // 16 | 32
+    static constexpr int kPhQuads = kPhRows * kX4;            // 1 568 | 3 136
+    static constexpr int kPieces = (kPhQuads + 63) / 64;      // 25 (the last one half used) | 49 DMA pieces of 1 KiB
+    static constexpr int kBufFloats = kPieces * 256;          // 25 600 | 50 176 B per buffer
+    static constexpr int kSlots = (kPieces + 7) / 8;          // pieces per wave: 4 | 7 (wave 0; the others one fewer)
+    static constexpr int kHooks = kPhRows / 4;                // side-work slots per phase: one per two row pairs (8 MFMAs)
+    static constexpr size_t kLdsBytes = (2 * (size_t)kBufFloats + kExFloats) * sizeof(float);   // 100 352 | 149 504
+    static_assert(kSlots <= kHooks, "two pieces are requested per hook in the first half of a phase");
+    static_assert(kHooks >= 4, "the four parts of the exchange are written from hooks 0..3");
+};
 
 // LDS-DMA through inline assembly (see conv_wino_ws.hip / vq_screen.hip)
 __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_dst) {
@@ -63,9 +68,11 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
                                                                      const float* __restrict__ bias, float* __restrict__ y, int ldx, int ldy,
                                                                      int Cin, int Lin, int Lout, int Cout, int relu, int ptiles,
                                                                      int64_t ntiles, int ncg, int nstreams, int xcd_map) {
-    constexpr int NPH = CINP / kPhRows;
+    using G = Geo<CINP>;
+    constexpr int kPhRows = G::kPhRows, kPhQuads = G::kPhQuads, kPieces = G::kPieces, kBufFloats = G::kBufFloats, kSlots = G::kSlots;
+    constexpr int NPH = 2;
     extern __shared__ __align__(16) float smem[];
-    float* const s_x = smem;                          // 2 x [16 rows][392]
+    float* const s_x = smem;                          // 2 x [CINP / 2 rows][392]
     float* const s_ex = smem + 2 * kBufFloats;        // exchange area
     const unsigned lds_x = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)s_x;
 
@@ -100,23 +107,29 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
     }
     const float bv = bias != nullptr ? bias[co] : 0.f;
     const float lo = relu ? 0.f : -INFINITY;
-    const float sgn = ti == 1 ? 1.f : -1.f;            // V1 = d2 + d1, V2 = d2 - d1 share one code path
 
     // ---- DMA pieces of this wave: piece p = wave + 8 k covers window quads 64 p .. 64 p + 63 (row = quad / 98, column quad = quad % 98)
-    int q_row[kSlots], q_c4[kSlots];
-#pragma unroll
-    for (int k = 0; k < kSlots; ++k) {
-        const int q = 64 * (wave + 8 * k) + lane;
-        q_row[k] = q / kX4;                            // 16 = past the phase's rows (tail of the last piece): zero source
-        q_c4[k] = q - q_row[k] * kX4;
-    }
+    // (the piece's first quad is wave-uniform: its row and column come off the scalar unit, a lane adds itself with one carry; no
+    // per-piece registers.  Row = kPhRows: past the phase's rows -- the tail of the last piece --: zero source)
+    auto piece_rc = [&](int k, int& qr, int& c4) {
+        const int A = 64 * (wave + 8 * k);
+        c4 = A % kX4 + lane;
+        const bool carry = c4 >= kX4;
+        c4 -= carry ? kX4 : 0;
+        qr = A / kX4 + (carry ? 1 : 0);
+    };
     const int npieces = wave < kPieces - 8 * (kSlots - 1) ? kSlots : kSlots - 1;
 
     auto request = [&](int64_t b, int pt, int ph, int buf, int k) {
         if (k >= npieces) return;                      // wave-uniform
-        const int row = ph * kPhRows + q_row[k];
-        const int g = pt * 384 - 4 + 4 * q_c4[k];
-        const float* a = (q_row[k] >= kPhRows || row >= Cin || g < 0 || g >= Lin) ? g_zero_quad_kw
+#if defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 2)
+        if (b != 0) return;   // (ablation: no window copies after the first epoch)
+#endif
+        int qr, c4;
+        piece_rc(k, qr, c4);
+        const int row = ph * kPhRows + qr;
+        const int g = pt * 384 - 4 + 4 * c4;
+        const float* a = (qr >= kPhRows || row >= Cin || g < 0 || g >= Lin) ? g_zero_quad_kw
                                                                                    : x + ((b * Cin + row) * (int64_t)ldx + g);
         lds_dma16(a, lds_x + (unsigned)(buf * kBufFloats + 256 * (wave + 8 * k)) * 4u);
     };
@@ -128,8 +141,10 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
 #pragma unroll
         for (int k = 0; k < kSlots; ++k) {
             if (k < npieces) {
-                const int g = ga + 4 * q_c4[k];
-                if (q_row[k] < kPhRows && g < Lin && g + 4 > Lin) {
+                int qr, c4;
+                piece_rc(k, qr, c4);
+                const int g = ga + 4 * c4;
+                if (qr < kPhRows && g < Lin && g + 4 > Lin) {
                     float* d = s_x + buf * kBufFloats + 256 * (wave + 8 * k) + 4 * lane;
 #pragma unroll
                     for (int e = 1; e < 4; ++e)
@@ -142,17 +157,21 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
     f32x16 acc[2][2];   // [tile parity][position sub-tile]
     // One phase = 8 input-row pairs = 32 MFMAs.  Window slot s of a row = sample 384 pt - 4 + s; W_k of row step j sits at slot 12 j + 3 + k:
     // quads A = W1..W4 (slot 12 j + 4), B = W5..W8, C = W9..W12, and the single samples W0 (slot 12 j + 3) and W13 (slot 12 j + 16).
-    auto mfma_phase = [&](auto kind_tag, auto par_tag, auto ph_tag, int buf, auto&& hook) {
-        constexpr int KIND = decltype(kind_tag)::value, P = decltype(par_tag)::value, PH = decltype(ph_tag)::value;
+    auto mfma_phase = [&](auto ti_tag, auto par_tag, auto ph_tag, int buf, auto&& hook) {
+        constexpr int TI = decltype(ti_tag)::value, P = decltype(par_tag)::value, PH = decltype(ph_tag)::value;
+        constexpr int KIND = TI == 0 ? 0 : TI == 3 ? 3 : 1;
         typedef const volatile __attribute__((address_space(3))) f4* lds_vf4;
         typedef const volatile __attribute__((address_space(3))) float* lds_vf1;
         const lds_vf4 xq = (lds_vf4)(s_x + buf * kBufFloats + h * kXW + 12 * j + 4);
         const lds_vf1 xe = (lds_vf1)(s_x + buf * kBufFloats + h * kXW + 12 * j + (KIND == 0 ? 3 : 16));
-        constexpr int NU = kPhRows / 2, RD = 2;   // sub-step = one row pair (4 MFMAs); the reads run RD sub-steps ahead of the MFMAs
+        constexpr int NU = kPhRows / 2, RD = 1;   // sub-step = one row pair (4 MFMAs); the reads run RD sub-steps ahead of the MFMAs
         f4 tq[RD + 1][3];
         float te[RD + 1] = {};
         float v[2][4];
         auto fetch = [&](int u, int set) {
+#if defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 4)
+            if (u > 0) { tq[set][0] = tq[0][0] + 1.f; tq[set][1] = tq[0][1]; tq[set][2] = tq[0][2]; te[set] = te[0]; return; }   // (ablation: one operand read per phase)
+#endif
             const int off = 2 * u * kXW;
             tq[set][0] = xq[off / 4];
             tq[set][1] = xq[off / 4 + 1];
@@ -165,11 +184,11 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
             const float e = te[u % (RD + 1)];
             float a, b;
             if (part == 0) {
-                if (KIND == 1) { a = fmaf(sgn, A.z, B.x); b = fmaf(sgn, C.x, C.z); }      // d1, d2 = W3 W5 | W9 W11
+                if (KIND == 1) { a = TI == 1 ? B.x + A.z : B.x - A.z; b = TI == 1 ? C.z + C.x : C.z - C.x; }   // d2 +- d1: W5 W3 | W11 W9
                 else if (KIND == 0) { a = A.x - B.x; b = B.z - C.z; }                     // d0 - d2 = W1 - W5 | W7 - W11
                 else { a = A.z - B.z; b = C.x - e; }                                      // d1 - d3 = W3 - W7 | W9 - W13
             } else {
-                if (KIND == 1) { a = fmaf(sgn, A.y, A.w); b = fmaf(sgn, B.w, C.y); }      // W2 W4 | W8 W10
+                if (KIND == 1) { a = TI == 1 ? A.w + A.y : A.w - A.y; b = TI == 1 ? C.y + B.w : C.y - B.w; }   // W4 W2 | W10 W8
                 else if (KIND == 0) { a = e - A.w; b = B.y - C.y; }                       // W0 - W4 | W6 - W10
                 else { a = A.y - B.y; b = B.w - C.w; }                                    // W2 - W6 | W8 - W12
             }
@@ -199,46 +218,64 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
             acc[P][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u & 1][3], ureg[t + 1], acc[P][1], 0, 0, 0);
             if (u + 1 < NU) form(u + 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (u & 1) hook(u >> 1);   // side work while these MFMAs occupy the pipe: window requests, the previous tile's exchange and outputs
+            if (u & 1) hook(u >> 1);   // (kHooks per phase) side work while these MFMAs occupy the pipe: window requests, the previous tile's exchange and outputs
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // exchange area: [wave][pm][register quad rq][lane] float4 -- register quad rq of a lane = rows 8 rq + 4 h + (0..3) of column j.
-    auto ex_write = [&](auto par_tag, int q) {
-        constexpr int P = decltype(par_tag)::value;
+    // exchange area: [wave][pm][slot][lane] float4 -- register quad rq of a lane = rows 8 rq + 4 h + (0..3) of column j; the wave of
+    // transform TI outputs quad TI and keeps its own share of it in registers, its other three quads go to slots 0..2 in order.
+    auto ex_write = [&](auto ti_tag, auto par_tag, int q) {
+        constexpr int TI = decltype(ti_tag)::value, P = decltype(par_tag)::value;
         const int pm = q >> 1;
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
             const int rq = 2 * (q & 1) + r2;
+            if (rq == TI) continue;
             f4 vv = {acc[P][pm][4 * rq], acc[P][pm][4 * rq + 1], acc[P][pm][4 * rq + 2], acc[P][pm][4 * rq + 3]};
-            reinterpret_cast<f4*>(s_ex)[((wave * 2 + pm) * 4 + rq) * 64 + lane] = vv;
+            reinterpret_cast<f4*>(s_ex)[((wave * 2 + pm) * 3 + (rq < TI ? rq : rq - 1)) * 64 + lane] = vv;
         }
     };
     // wave (ti, c32) forms register quad ti of channel group c32.  Row r = 8 ti + 4 h + e holds triple 2 r + pm: the two sub-tiles of a row are
     // six consecutive outputs, a lane's four rows 24 of them: six 16-byte stores, 96 contiguous bytes per lane.
-    auto ex_output = [&](int64_t b, int pt) {
+    auto ex_output = [&](auto ti_tag, auto par_tag, int64_t b, int pt, int eh_lo, int eh_hi) {
+        constexpr int TI = decltype(ti_tag)::value, P = decltype(par_tag)::value;   // P: the accumulator set of the tile being output
         float* yr = y + (b * Cout + co) * (int64_t)ldy;
-        f4 m[2][4];
-#pragma unroll
-        for (int pm = 0; pm < 2; ++pm)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) m[pm][k] = reinterpret_cast<const f4*>(s_ex)[(((k + 4 * c32) * 2 + pm) * 4 + ti) * 64 + lane];
-        float o[24];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int pm = 0; pm < 2; ++pm) {
-                const float m0 = m[pm][0][e], m1 = m[pm][1][e], m2 = m[pm][2][e], m3 = m[pm][3][e];
-                o[6 * e + 3 * pm] = fmaxf(((m0 + m1) + m2) + bv, lo);
-                o[6 * e + 3 * pm + 1] = fmaxf((m1 - m2) + bv, lo);
-                o[6 * e + 3 * pm + 2] = fmaxf(((m1 + m2) - m3) + bv, lo);
-            }
         const int p0 = pt * 192 + 48 * ti + 24 * h;
+        typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const int p = p0 + 4 * s;
-            // ldy is a multiple of 4 >= Lout: the tail quad may spill into the row's pitch padding (finite values)
-            if (p < Lout) *reinterpret_cast<f4*>(yr + p) = (f4){o[4 * s], o[4 * s + 1], o[4 * s + 2], o[4 * s + 3]};
+        for (int eh = eh_lo; eh < eh_hi; ++eh) {   // rows e = 2 eh, 2 eh + 1 at a time (12 outputs, three stores): 16 + 12 registers live, not 32 + 24
+            f2 m[2][4];
+#pragma unroll
+            for (int pm = 0; pm < 2; ++pm)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k == TI) m[pm][k] = (f2){acc[P][pm][4 * TI + 2 * eh], acc[P][pm][4 * TI + 2 * eh + 1]};
+                    else m[pm][k] = reinterpret_cast<const f2*>(s_ex)[((((k + 4 * c32) * 2 + pm) * 3 + (TI < k ? TI : TI - 1)) * 64 + lane) * 2 + eh];
+                }
+            float o[12];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int pm = 0; pm < 2; ++pm) {
+                    const float m0 = m[pm][0][e], m1 = m[pm][1][e], m2 = m[pm][2][e], m3 = m[pm][3][e];
+                    o[6 * e + 3 * pm] = fmaxf(((m0 + m1) + m2) + bv, lo);
+                    o[6 * e + 3 * pm + 1] = fmaxf((m1 - m2) + bv, lo);
+                    o[6 * e + 3 * pm + 2] = fmaxf(((m1 + m2) - m3) + bv, lo);
+                }
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int p = p0 + 12 * eh + 4 * s3;
+                // ldy is a multiple of 4 >= Lout: the tail quad may spill into the row's pitch padding (finite values)
+#if defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 1)
+                if (o[4 * s3] + o[4 * s3 + 1] + o[4 * s3 + 2] + o[4 * s3 + 3] == 123.456f) yr[p] = 0.f;   // (ablation: no stores)
+#elif defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 16)
+                // (ablation: the same number of 16-byte stores, but a wave's 64 lanes write 1 KiB of consecutive addresses -- wrong places)
+                if (p < Lout) *reinterpret_cast<f4*>(y + ((b * Cout + cg * 64 + wave * 8) * (int64_t)ldy + pt * 192 + (eh * 3 + s3) * 256 + 4 * lane) % ((int64_t)Cout * ldy * 16384 - 1024) / 4 * 4) = (f4){o[4 * s3], o[4 * s3 + 1], o[4 * s3 + 2], o[4 * s3 + 3]};
+#else
+                if (p < Lout) *reinterpret_cast<f4*>(yr + p) = (f4){o[4 * s3], o[4 * s3 + 1], o[4 * s3 + 2], o[4 * s3 + 3]};
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -255,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
 #pragma unroll
     for (int k = 0; k < kSlots; ++k) request(b, pt, 0, 0, k);
     // one tile into accumulator set P; returns true after the last tile of the walk (whose exchange it then completes)
-    auto tile_step = [&](auto kind_tag, auto par_tag) -> bool {
+    auto tile_step = [&](auto ti_tag, auto par_tag) -> bool {
         constexpr int P = decltype(par_tag)::value;
         const std::integral_constant<int, 1 - P> other{};
         int64_t nb = b + db;
@@ -269,21 +306,37 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
             fix_edges(pt, PH & 1);
             __syncthreads();   // this phase's rows are in buffer PH & 1; every wave is done with the other buffer (and, in phase 1, has
                                // written the previous tile's transforms; in phase 0, has read the outputs of the tile before that)
-            mfma_phase(kind_tag, par_tag, ph_tag, PH & 1, [&](int g) {
-                if (g < 2) {   // the next phase's window (the next tile's first one in the last phase) into the other buffer
-                    if (PH + 1 < NPH) { request(b, pt, PH + 1, (PH + 1) & 1, 2 * g); request(b, pt, PH + 1, (PH + 1) & 1, 2 * g + 1); }
-                    else if (more) { request(nb, npt, 0, 0, 2 * g); request(nb, npt, 0, 0, 2 * g + 1); }
+            mfma_phase(ti_tag, par_tag, ph_tag, PH & 1, [&](int g) {
+// (measured, profiles/r03_experiments.md: the previous tile's stores issued well BEHIND the window requests -- hook 5 of 8 / 2 of 4 --
+// instead of next to them: layer 2 3.14 -> 2.95 ms, layer 1 2.05 -> 1.85 ms; at the last hooks they are not done by the phase's end)
+#ifndef LBM_KW_OUT_HOOK
+#define LBM_KW_OUT_HOOK (5 * G::kHooks / 8)
+#endif
+#ifndef LBM_KW_OUT_HOOK_B
+#define LBM_KW_OUT_HOOK_B LBM_KW_OUT_HOOK
+#endif
+#ifndef LBM_KW_EXW_HOOK0
+#define LBM_KW_EXW_HOOK0 0
+#endif
+#ifndef LBM_KW_REQ_HOOK0
+#define LBM_KW_REQ_HOOK0 0
+#endif
+                const int gr = g - LBM_KW_REQ_HOOK0;
+                if (gr >= 0 && 2 * gr < kSlots) {   // the next phase's window (the next tile's first one in the last phase) into the other buffer
+                    if (PH + 1 < NPH) { request(b, pt, PH + 1, (PH + 1) & 1, 2 * gr); request(b, pt, PH + 1, (PH + 1) & 1, 2 * gr + 1); }
+                    else if (more) { request(nb, npt, 0, 0, 2 * gr); request(nb, npt, 0, 0, 2 * gr + 1); }
                 }
-                if (PH == 0 && have_prev) ex_write(other, g);
-                if (PH == (NPH > 2 ? 2 : 1) && g == 1 && have_prev) ex_output(pb, ppt);
+#if defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 8)
+                if (PH == 1 && g == 0 && have_prev && bv == 123.456f) { ex_write(ti_tag, other, 0); ex_output(ti_tag, other, pb, ppt, 0, 2); }   // (ablation: no exchange)
+#else
+                if (PH == 0 && g >= LBM_KW_EXW_HOOK0 && g < LBM_KW_EXW_HOOK0 + 4 && have_prev) ex_write(ti_tag, other, g - LBM_KW_EXW_HOOK0);
+                if (PH == 1 && g == LBM_KW_OUT_HOOK && have_prev) ex_output(ti_tag, other, pb, ppt, 0, 1);
+                if (PH == 1 && g == LBM_KW_OUT_HOOK_B && have_prev) ex_output(ti_tag, other, pb, ppt, 1, 2);
+#endif
             });
         };
         phase(std::integral_constant<int, 0>{});
         phase(std::integral_constant<int, 1>{});
-        if constexpr (NPH > 2) {
-            phase(std::integral_constant<int, 2>{});
-            phase(std::integral_constant<int, 3>{});
-        }
         pb = b; ppt = pt; have_prev = true;
         if (more) {
             tile = ntile; b = nb; pt = npt;
@@ -291,20 +344,22 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
         }
         __syncthreads();           // the exchange area is free again
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ex_write(par_tag, q);
+        for (int q = 0; q < 4; ++q) ex_write(ti_tag, par_tag, q);
         __syncthreads();
-        ex_output(pb, ppt);
+        ex_output(ti_tag, par_tag, pb, ppt, 0, 2);
         return true;
     };
-    auto walk = [&](auto kind_tag) {
+    auto walk = [&](auto ti_tag) {
         while (true) {
-            if (tile_step(kind_tag, std::integral_constant<int, 0>{})) break;
-            if (tile_step(kind_tag, std::integral_constant<int, 1>{})) break;
+            if (tile_step(ti_tag, std::integral_constant<int, 0>{})) break;
+            if (tile_step(ti_tag, std::integral_constant<int, 1>{})) break;
         }
     };
-    if (ti == 0) walk(std::integral_constant<int, 0>{});          // wave-uniform: three instances of the walk that differ in the operand reads
-    else if (ti == 3) walk(std::integral_constant<int, 3>{});
-    else walk(std::integral_constant<int, 1>{});
+    // wave-uniform: one instance of the walk per transform (operand reads, exchange slots and the output quad are compile-time)
+    if (ti == 0) walk(std::integral_constant<int, 0>{});
+    else if (ti == 1) walk(std::integral_constant<int, 1>{});
+    else if (ti == 2) walk(std::integral_constant<int, 2>{});
+    else walk(std::integral_constant<int, 3>{});
 }
 
 int g_cus_kw[64];   // multiprocessor count per device (0 = not asked yet)
@@ -325,10 +380,12 @@ int launch_k4s2_wino(const float* x, const float* w, const float* bias, float* y
     if (g_cus_kw[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        for (const void* k : {reinterpret_cast<const void*>(conv_k4s2_wino_ws_kernel<32>), reinterpret_cast<const void*>(conv_k4s2_wino_ws_kernel<64>)}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
-            if (e != hipSuccess) return fail(LBM_ELAUNCH, "lbm_conv1d_k4s2_wino_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_k4s2_wino_ws_kernel<32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Geo<32>::kLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_k4s2_wino_ws_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)Geo<64>::kLdsBytes);
+        if (e != hipSuccess) return fail(LBM_ELAUNCH, "lbm_conv1d_k4s2_wino_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
         g_cus_kw[dev] = n;
     }
     const int ntr = (Lout + 2) / 3;                 // output triples per row
@@ -347,7 +404,7 @@ int launch_k4s2_wino(const float* x, const float* w, const float* bias, float* y
         xcd_map = 0;
     }
     auto k = Cin <= 32 ? conv_k4s2_wino_ws_kernel<32> : conv_k4s2_wino_ws_kernel<64>;
-    hipLaunchKernelGGL(k, dim3((unsigned)(nstreams * ncg)), dim3(kThreads), kLdsBytes, st, x, w, bias, y, (int)ldx, (int)ldy, Cin, Lin, Lout,
+    hipLaunchKernelGGL(k, dim3((unsigned)(nstreams * ncg)), dim3(kThreads), Cin <= 32 ? Geo<32>::kLdsBytes : Geo<64>::kLdsBytes, st, x, w, bias, y, (int)ldx, (int)ldy, Cin, Lin, Lout,
                        Cout, relu, ptiles, ntiles, ncg, nstreams, xcd_map);
     return check_launch("lbm_conv1d_k4s2_wino_f32");
 }

@@ -320,7 +320,10 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_ws_kernel(const float* __
                 if (g == 1) { request(nb, npt, 0, 0, 2); request(nb, npt, 0, 0, 3); }
                 if (g == 2) request(nb, npt, 0, 0, 4);
             }
-            if (g == 3 && have_prev) ex_output(pb, ppt);
+#ifndef LBM_WS_OUT_HOOK
+#define LBM_WS_OUT_HOOK 3
+#endif
+            if (g == LBM_WS_OUT_HOOK && have_prev) ex_output(pb, ppt);
         });
         WS_STAMP(8);
         pb = b; ppt = pt; have_prev = true;
