@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--dense", action="store_true", help="conv stages: dense rows (pitch = length) instead of 16-byte rows")
     ap.add_argument("--samples", type=int, default=1_800_000, help="ica stages: recording length")
     ap.add_argument("--split", action="store_true", help="conv stages: the bf16x6 kernel over pre-split weight tables")
+    ap.add_argument("--direct", action="store_true", help="conv1 / conv2: the direct-form kernel instead of the F(3,2) one")
     ap.add_argument("--cin", type=int, default=0, help="conv stages: override the input channel count (random weights)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -110,6 +111,9 @@ def main():
         xin = rnd(E, cin, ldx)
         yo = torch.empty(E, cout, ldy, device=dev)
         fn = lambda: lib.lbm_conv1d_pitched_f32(p(xin), ldx, p(wt), p(bs), p(yo), ldy, E, cin, lin, cout, ks, sd, pd, relu, st)  # noqa: E731
+        if ks == 4 and not args.split and not args.dense and not args.direct and lib.lbm_conv1d_k4s2_wino_supported(cin, cout):
+            # layers 1 and 2 as the pipeline runs them: two 2-tap phases in F(3,2) (--direct: lbm_conv1d_pitched_f32)
+            fn = lambda: lib.lbm_conv1d_k4s2_wino_f32(p(xin), ldx, p(wt), p(bs), p(yo), ldy, E, cin, lin, cout, relu, st)  # noqa: E731
         if s == "conv3" and not args.split and not args.cin and not args.dense:   # as the pipeline runs it: transformed weights from a table
             wtab = lbm_amd.conv_wino3_tables(wt)
             fn = lambda: lib.lbm_conv1d_wino3_f32(p(xin), ldx, p(wtab), p(bs), p(yo), ldy, E, cin, lin, cout, relu, st)  # noqa: E731

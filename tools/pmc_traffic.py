@@ -9,7 +9,7 @@ import sys
 
 root = sys.argv[1]
 E, C, T, S = 16384, 30, 1500, 375
-KERNEL = {"vq": "vq_argmin_dma_kernel", "vqs": "vq_screen_pipe_kernel", "vqb": "vq_bf16x6_kernel", "conv1": "conv_k4s2_ws_kernel<30", "conv2": "conv_k4s2_ws_kernel<64", "conv3": "conv_wino3_ws_kernel", "conv4": "conv_tile_kernel<1, 1, 256",
+KERNEL = {"vq": "vq_argmin_dma_kernel", "vqs": "vq_screen_pipe_kernel", "vqb": "vq_bf16x6_kernel", "conv1": "conv_k4s2_wino_ws_kernel<32", "conv2": "conv_k4s2_wino_ws_kernel<64", "conv3": "conv_wino3_ws_kernel", "conv4": "conv_tile_kernel<1, 1, 256",
           "fir": "fir_fft_kernel", "welch_scaled": "welch_team_kernel", "affine_post": "affine_post_kernel"}
 OUTKEY = {"vqs": "vq_screen", "vqb": "vq_bf16x6"}     # bench.py looks the quantizer up as vq_<method>
 ALGO = {"vq": (256 * S * 4 + S * 8) * E, "vqs": (256 * S * 4 + S * 8) * E, "vqb": (256 * S * 4 + S * 8) * E, "conv1": (C * T * 4 + 64 * 750 * 4) * E, "conv2": (64 * 750 * 4 + 128 * S * 4) * E, "conv3": (128 * S * 4 + 256 * S * 4) * E,
