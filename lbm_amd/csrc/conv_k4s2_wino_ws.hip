@@ -119,19 +119,32 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
         qr = A / kX4 + (carry ? 1 : 0);
     };
     const int npieces = wave < kPieces - 8 * (kSlots - 1) ? kSlots : kSlots - 1;
+    // the zero source's address lives in a register pair: fetched per request it costs a scalar load and a wait that also drains the LDS queue
+    const float* vzero = g_zero_quad_kw;
+    asm volatile("" : "+v"(vzero));
 
     auto request = [&](int64_t b, int pt, int ph, int buf, int k) {
         if (k >= npieces) return;                      // wave-uniform
 #if defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 2)
         if (b != 0) return;   // (ablation: no window copies after the first epoch)
 #endif
+#if defined(LBM_KW_ABLATE) && (LBM_KW_ABLATE & 32)
+        // (ablation: the same number of copies, no address arithmetic: every piece copies the first KiB of the epoch)
+        { lds_dma16(x + (b * Cin * (int64_t)ldx + 4 * lane), lds_x + (unsigned)(buf * kBufFloats + 256 * (wave + 8 * k)) * 4u); return; }
+#endif
         int qr, c4;
         piece_rc(k, qr, c4);
-        const int row = ph * kPhRows + qr;
+        // wave-uniform 64-bit base (scalar unit) + a 32-bit lane offset (one 24-bit multiply-add); branch-free choice of the source
+        const int row0 = ph * kPhRows;
+        const float* base = x + (b * Cin + row0) * (int64_t)ldx;
         const int g = pt * 384 - 4 + 4 * c4;
-        const float* a = (qr >= kPhRows || row >= Cin || g < 0 || g >= Lin) ? g_zero_quad_kw
-                                                                                   : x + ((b * Cin + row) * (int64_t)ldx + g);
-        lds_dma16(a, lds_x + (unsigned)(buf * kBufFloats + 256 * (wave + 8 * k)) * 4u);
+        const bool ok = qr < kPhRows && row0 + qr < Cin && (unsigned)g < (unsigned)Lin;
+        const unsigned off = __umul24((unsigned)qr, (unsigned)ldx) + (unsigned)g;      // qr <= 32, ldx < 2^24 (launcher)
+        const float* src = base + off;
+        const unsigned long long sa = (unsigned long long)src, za = (unsigned long long)vzero;
+        const unsigned lo32 = ok ? (unsigned)sa : (unsigned)za, hi32 = ok ? (unsigned)(sa >> 32) : (unsigned)(za >> 32);
+        lds_dma16(reinterpret_cast<const float*>(((unsigned long long)hi32 << 32) | lo32),
+                  lds_x + (unsigned)(buf * kBufFloats + 256 * (wave + 8 * k)) * 4u);
     };
     // After this wave's pieces have landed: the quad that straddles a row's end (Lin not a multiple of 4) holds pitch padding behind the
     // last real sample; the lane that copied it zeroes that.  Wave-uniform test first.
@@ -369,7 +382,7 @@ int g_cus_kw[64];   // multiprocessor count per device (0 = not asked yet)
 namespace lbm {
 
 bool k4s2_wino_eligible(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, int Cin, int Cout, int Lin) {
-    return Cin >= 1 && Cin <= 64 && Cout % 64 == 0 && Cout >= 64 && Lin >= 2 && ldx % 4 == 0 && ldy % 4 == 0 &&
+    return Cin >= 1 && Cin <= 64 && Cout % 64 == 0 && Cout >= 64 && Lin >= 2 && ldx % 4 == 0 && ldy % 4 == 0 && ldx < (1 << 24) &&
            ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w)) & 15) == 0;
 }
 
