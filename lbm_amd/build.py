@@ -70,7 +70,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flags = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
     # The FFT kernels keep complex values as split re/im registers; the SLP vectorizer pairs them into packed-fp32 ops
     # and pays for it with register moves (fir_fft_kernel: 384 v_mov per item, 16 B of scratch; 3.9 -> 3.2 ms without).
-    no_slp = {"fir_fft.hip", "welch.hip", "resample.hip"}
+    # Round 3: the same flag for three MFMA kernels whose side arithmetic hipcc had packed (v_pk_add_f32 beside MFMAs costs more than the
+    # two scalar adds, MI355X_MICROARCH.md): screening 4.756 -> 4.718 ms, affine_post 1.540 -> 1.523, the F(3,2) conv layers -0.4 % (A/B x2).
+    no_slp = {"fir_fft.hip", "welch.hip", "resample.hip", "vq_screen.hip", "conv_k4s2_wino_ws.hip", "affine_post.hip"}
     procs = []
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")

@@ -44,7 +44,7 @@ def main():
     src = os.path.join(B.CSRC, a.source)
     base = os.path.basename(src)
     flags = ["-O3", "-std=c++17", f"--offload-arch={B.ARCH}", "-fPIC", "-munsafe-fp-atomics"]
-    if base in {"fir_fft.hip", "welch.hip", "resample.hip"}:
+    if base in {"fir_fft.hip", "welch.hip", "resample.hip", "vq_screen.hip", "conv_k4s2_wino_ws.hip", "affine_post.hip"}:
         flags += ["-fno-slp-vectorize"]
     if base == "vq.hip":
         flags += ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
