@@ -95,13 +95,15 @@ __global__ __launch_bounds__(64 * NCG * NPG) void conv_k4s2_ws_kernel(const floa
     const int npieces = wave < Cfg::PIECES - NW * (SLOTS - 1) ? SLOTS : SLOTS - 1;
     // Requests piece k of this wave (window quads 64 (wave + 8 k) ..) of tile (b, pt) into buffer `buf`.  Quads wholly outside [0, Lin)
     // come from g_zero_quad_k4, so only the one quad per row that straddles the row's end needs fixing afterwards.
+    const float* vzero = g_zero_quad_k4;   // (in a register pair: fetched per request it is a scalar load through the GOT + an lgkmcnt(0) wait)
+    asm volatile("" : "+v"(vzero));
     auto request = [&](int64_t b, int pt, int buf, int k) {
         if (k >= npieces) return;                               // wave-uniform
         const int q = 64 * (wave + NW * k) + lane;
         const int row = q / X4, c4 = q - row * X4;
         const int g = 2 * pt * TP - 4 + 4 * c4;
         const float* src = x + b * (int64_t)CIN * ldx;
-        const float* a = (q >= Cfg::QUADS || g < 0 || g >= Lin) ? g_zero_quad_k4 : src + (row * ldx + g);
+        const float* a = (q >= Cfg::QUADS || g < 0 || g >= Lin) ? vzero : src + (row * ldx + g);
         lds_dma16(a, lds_x + (unsigned)(buf * Cfg::BUF_FLOATS + 256 * (wave + NW * k)) * 4u);
     };
     auto fix_edges = [&](int pt, int buf) {

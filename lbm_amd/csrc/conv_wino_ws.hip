@@ -128,6 +128,9 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_ws_kernel(const float* __
 
     // Requests piece k of this wave for half `half` of tile (b, pt) into buffer `buf`.  A quad wholly outside [0, Lin) -- the zero padding
     // left of a row, everything right of its end -- is copied from g_zero_quad instead, so it needs no fixing afterwards.
+    // (the zero source's address in a register pair: fetched per request it is a scalar load through the GOT + an `lgkmcnt(0)` wait)
+    const float* vzero = g_zero_quad;
+    asm volatile("" : "+v"(vzero));
     auto request = [&](int64_t b, int pt, int half, int buf, int k) {
 #if defined(LBM_WS_ABLATE) && (LBM_WS_ABLATE & 2)
         if (b != 0) return;   // (ablation: no window copies after the first epoch)
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_ws_kernel(const float* __
         if (k >= npieces) return;                      // wave-uniform
         const float* src = x + (b * kCin + half * kHalfRows) * (int64_t)ldx;
         const int g = pt * 128 - 4 + 4 * q_c4[k];
-        const float* a = (g < 0 || g >= Lin) ? g_zero_quad : src + (q_row[k] * ldx + g);
+        const float* a = (g < 0 || g >= Lin) ? vzero : src + (q_row[k] * ldx + g);
         lds_dma16(a, lds_x + (unsigned)(buf * kHalfFloats + 256 * (wave + 8 * k)) * 4u);
     };
     // After this wave's pieces have landed: the one quad per row that straddles the row's end (Lin not a multiple of 4) still holds
