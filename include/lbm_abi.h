@@ -283,7 +283,8 @@ int lbm_conv1d_wino3_f32(const float* x, int64_t ldx, const void* tables, const 
  * lbm_conv1d_pitched_f32's by rounding only (both within ~1e-6 of a float64 convolution at the encoder's scales) and are NOT
  * bit-identical to it.  Supported (lbm_conv1d_k4s2_wino_supported != 0): 1 <= Cin <= 64, Cout a multiple of 64; rows must be 16-byte
  * pitched (ldx, ldy multiples of 4) and x, w, y 16-byte aligned, otherwise LBM_EUNSUPPORTED (callers then use lbm_conv1d_pitched_f32).
- * w is [Cout, Cin, 4]; x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32; Lout = (Lin - 2) / 2 + 1. */
+ * w is [Cout, Cin, 4]; x, y, ldx, ldy, bias, relu as for lbm_conv1d_pitched_f32; Lout = (Lin - 2) / 2 + 1.  The first call on a device
+ * sets the kernels' dynamic-LDS attribute (warm up before graph capture, as for lbm_conv1d_wino3_f32). */
 int lbm_conv1d_k4s2_wino_supported(int32_t Cin, int32_t Cout);
 int lbm_conv1d_k4s2_wino_f32(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy, int64_t B,
                              int32_t Cin, int32_t Lin, int32_t Cout, int32_t relu, lbm_stream_t stream);

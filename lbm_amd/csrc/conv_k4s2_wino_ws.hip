@@ -15,9 +15,12 @@
 //
 // Work layout = conv_wino3_ws_kernel's (conv_wino_ws.hip): a WAVE owns one transform i and 32 output channels for the whole launch, its
 // U_i[32][2 Cin] is the MFMA B operand in registers; persistent 8-wave workgroups (4 transforms x 2 channel groups, one per CU) walk
-// tiles of 64 output triples (192 positions); only the raw input window moves -- 16 input rows x 392 samples (25 KB) per phase, by LDS-DMA
-// into one of two buffers, requested under the previous phase's MFMAs; the four transforms of an output meet in a 64 KB LDS exchange area
-// under the next tile's MFMAs (two accumulator sets).  Row r of position sub-tile pm is triple 2 r + pm, so a lane's two triples are
+// tiles of 64 output triples (192 positions); only the raw input window moves -- Cin / 2 input rows x 392 samples (25 | 49 KB) per phase,
+// two phases per tile, by LDS-DMA into one of two buffers, requested under the previous phase's MFMAs; the four transforms of an output
+// meet in a 48 KB LDS exchange area under the next tile's MFMAs (two accumulator sets; the register quad a wave outputs itself never
+// leaves its registers, which is why there is one instance of the tile walk per transform: operand picks, exchange slots and the own
+// quad are compile-time).  The previous tile's stores are issued well behind the window requests (hook 5 of 8 / 2 of 4: next to them
+// they queue in front of the requests; measurements in profiles/r03_experiments.md).  Row r of position sub-tile pm is triple 2 r + pm, so a lane's two triples are
 // neighbours: the 14 samples W0..W13 = x[6 (2 r) - 1 ...] they need from one input row sit in three aligned 16-byte quads (+ one
 // sample for transforms 0 and 3), read once for 4 MFMAs (2 phases x 2 sub-tiles):
 //   even phase  sub-tile 0: d = W1 W3 W5 W7     sub-tile 1: d = W7 W9 W11 W13
