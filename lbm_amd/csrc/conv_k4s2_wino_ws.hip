@@ -255,7 +255,8 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
     // six consecutive outputs, a lane's four rows 24 of them: six 16-byte stores, 96 contiguous bytes per lane.
     auto ex_output = [&](auto ti_tag, auto par_tag, int64_t b, int pt, int eh_lo, int eh_hi) {
         constexpr int TI = decltype(ti_tag)::value, P = decltype(par_tag)::value;   // P: the accumulator set of the tile being output
-        float* yr = y + (b * Cout + co) * (int64_t)ldy;
+        // (row base: the wave-uniform part in 64 bits on the scalar unit, the lane's channel as one 24-bit multiply)
+        float* yr = y + (b * Cout + (cg * 64 + c32 * 32)) * (int64_t)ldy + __umul24((unsigned)j, (unsigned)ldy);
         const int p0 = pt * 192 + 48 * ti + 24 * h;
         typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -385,7 +386,7 @@ int g_cus_kw[64];   // multiprocessor count per device (0 = not asked yet)
 namespace lbm {
 
 bool k4s2_wino_eligible(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, int Cin, int Cout, int Lin) {
-    return Cin >= 1 && Cin <= 64 && Cout % 64 == 0 && Cout >= 64 && Lin >= 2 && ldx % 4 == 0 && ldy % 4 == 0 && ldx < (1 << 24) &&
+    return Cin >= 1 && Cin <= 64 && Cout % 64 == 0 && Cout >= 64 && Lin >= 2 && ldx % 4 == 0 && ldy % 4 == 0 && ldx < (1 << 24) && ldy < (1 << 24) &&
            ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w)) & 15) == 0;
 }
 

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(kThreads) void conv_wino3_ws_kernel(const float* __
     // wave (ti, c32) forms register quad ti of channel group c32.  Row r = 8 ti + 4 h + e holds pair 2 r + pm, so the two sub-tiles of a row
     // are four consecutive outputs and a lane's four rows 16 of them: four 16-byte stores, 64 contiguous bytes per lane.
     auto ex_output = [&](int64_t b, int pt) {
-        float* yr = y + (b * Cout + co) * (int64_t)ldy;
+        // (row base: the wave-uniform part in 64 bits on the scalar unit, the lane's channel as one 24-bit multiply)
+        float* yr = y + (b * Cout + (cg * 64 + c32 * 32)) * (int64_t)ldy + __umul24((unsigned)j, (unsigned)ldy);
         f4 m[2][4];
 #pragma unroll
         for (int pm = 0; pm < 2; ++pm)
@@ -376,7 +377,7 @@ extern "C" int lbm_debug_ws_stamps(unsigned long long* p) { return (int)hipMemcp
 namespace lbm {
 
 bool wino3_ws_eligible(const float* x, int64_t ldx, const float* y, int64_t ldy, int Cin, int Cout) {
-    return Cin == kCin && Cout % 64 == 0 && Cout >= 64 && ldx % 4 == 0 && ldy % 4 == 0 &&
+    return Cin == kCin && Cout % 64 == 0 && Cout >= 64 && ldx % 4 == 0 && ldy % 4 == 0 && ldy < (1 << 24) &&
            ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
 }
 
