@@ -274,7 +274,9 @@ __global__ __launch_bounds__(kThreads) void conv_k4s2_wino_ws_kernel(const float
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int pm = 0; pm < 2; ++pm) {
-                    const float m0 = m[pm][0][e], m1 = m[pm][1][e], m2 = m[pm][2][e], m3 = m[pm][3][e];
+                    float m0 = m[pm][0][e], m1 = m[pm][1][e], m2 = m[pm][2][e], m3 = m[pm][3][e];
+                    asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3));   // scalars: hipcc otherwise pairs the adds of e = 0, 1 into
+                                                                                  // v_pk_add_f32, which costs more beside MFMAs than the pair
                     o[6 * e + 3 * pm] = fmaxf(((m0 + m1) + m2) + bv, lo);
                     o[6 * e + 3 * pm + 1] = fmaxf((m1 - m2) + bv, lo);
                     o[6 * e + 3 * pm + 2] = fmaxf(((m1 + m2) - m3) + bv, lo);
