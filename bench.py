@@ -681,7 +681,8 @@ def run_rank(args):
     if rank == 0 and args.vq == "screen":
         kw = dict(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb, emit_cleaned=args.emit_cleaned, conv_method=args.conv,
                   conv_k4s2=args.conv_k4s2, fold_projection=args.fold_proj)
-        ref_pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(vq_method="fp32", **kw), taps, A, b, weights, codebook, device=dev)
+        ref_pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(vq_method="fp32", dedup_codes=False, **kw), taps, A, b, weights, codebook,
+                                         device=dev)      # all K rows of the codebook, every row of the input, in fp32
         ref_pipe._buf, ref_pipe._cap = {**pipe._buf}, pipe._cap          # share the stage buffers (z too, if unfolded)
         ref_pipe._buf["tokens"] = torch.empty_like(pipe._buf["tokens"])
         ref_pipe._buf["hist"] = torch.zeros_like(pipe._buf["hist"])
@@ -784,7 +785,7 @@ def run_rank(args):
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "conv_k4s2": args.conv_k4s2, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                       "codebook": K, "codes_searched": int(pipe.K_used), "distinct_codes": int(pipe.K_real), "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "conv_k4s2": args.conv_k4s2, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
                        "collectives": coll, "backend": args.backend if xch is not None else None},
             "roofline": roof,

@@ -369,6 +369,16 @@ int lbm_vq_ema_apply_f32(float* ema_cluster_size, float* ema_w, float* weight, c
                          const unsigned long long* counts, int32_t K, int32_t D, float decay, float one_minus_decay,
                          float eps, lbm_stream_t stream);
 
+/* Searching a sub-codebook (round 3).  VectorQuantizerEMA.get_code_indices (training/model.py:152-158) takes the FIRST minimum, so a code
+ * row that repeats an earlier row bit for bit (together with its e_sqnorm) can never be returned: callers may search the codebook with such
+ * rows removed -- the shipped checkpoint has 100 all-zero rows among its 512 -- and translate the indices back.  code_map [Kc] maps a
+ * searched row to the caller's code number (ascending, so ties keep resolving to the lowest original index).  In place: idx[i] <-
+ * code_map[idx[i]] for 0 <= idx[i] < Kc (idx 16-byte aligned); with the two histograms, hist[code_map[k]] += hist_c[k] and hist_c[k] <- 0
+ * (hist_c: the counts the search accumulated over searched rows; both or neither).  No counterpart in the reference (it searches all rows);
+ * the host side is lbm_amd.quantizer.dedup_codebook. */
+int lbm_vq_remap_codes_i64(int64_t* idx, int64_t N, const int64_t* code_map, int32_t Kc, unsigned long long* hist_c_or_null,
+                           unsigned long long* hist_or_null, lbm_stream_t stream);
+
 /* training/model.py:142-144: perplexity = exp(-sum(p * log(p + 1e-10))), p = hist / sum(hist). out: [1]. */
 int lbm_perplexity_u64(const unsigned long long* hist, float* out, int32_t K, lbm_stream_t stream);
 

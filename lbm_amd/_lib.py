@@ -52,6 +52,7 @@ SIGNATURES = {
     "lbm_bandpower_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_pitched_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "lbm_vq_remap_codes_i64": (C.c_int, [_p, _i64, _p, _i32, _p, _p, _p]),
     "lbm_conv1d_k4s2_wino_supported": (C.c_int, [_i32, _i32]),
     "lbm_conv1d_k4s2_wino_f32": (C.c_int, [_p, _i64, _p, _p, _p, _i64, _i64, _i32, _i32, _i32, _i32, _p]),
     "lbm_conv1d_wino3_tables_bytes": (C.c_size_t, [_i32, _i32]),

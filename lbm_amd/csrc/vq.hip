@@ -532,6 +532,61 @@ extern "C" int lbm_vq_gather_loss_f32(const float* x, const float* codebook, con
     return lbm::check_launch("lbm_vq_gather_loss_f32");
 }
 
+namespace {
+
+// idx[i] <- code_map[idx[i]]: tokens of a searched sub-codebook back to the caller's code numbers (16 bytes = two tokens per access)
+__global__ __launch_bounds__(256) void vq_remap_kernel(int64_t* __restrict__ idx, int64_t N, const int64_t* __restrict__ code_map, int Kc) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t pairs = N >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
+        longlong2 v = reinterpret_cast<longlong2*>(idx)[i];
+        v.x = (v.x >= 0 && v.x < Kc) ? code_map[v.x] : v.x;
+        v.y = (v.y >= 0 && v.y < Kc) ? code_map[v.y] : v.y;
+        reinterpret_cast<longlong2*>(idx)[i] = v;
+    }
+    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t v = idx[N - 1];
+        if (v >= 0 && v < Kc) idx[N - 1] = code_map[v];
+    }
+}
+
+// hist[code_map[k]] += hist_c[k]; hist_c[k] <- 0.  code_map is injective on [0, Kc): no two k meet in one bin.
+__global__ __launch_bounds__(256) void vq_remap_hist_kernel(unsigned long long* __restrict__ hist_c, unsigned long long* __restrict__ hist,
+                                                            const int64_t* __restrict__ code_map, int Kc) {
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < Kc; k += gridDim.x * 256) {
+        const unsigned long long c = hist_c[k];
+        if (c != 0) {
+            hist[code_map[k]] += c;
+            hist_c[k] = 0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int lbm_vq_remap_codes_i64(int64_t* idx, int64_t N, const int64_t* code_map, int32_t Kc, unsigned long long* hist_c_or_null,
+                                      unsigned long long* hist_or_null, lbm_stream_t stream) {
+    LBM_REQUIRE(N >= 0 && Kc >= 1, LBM_EINVAL, "lbm_vq_remap_codes_i64: bad sizes (N=%lld, Kc=%d)", (long long)N, Kc);
+    LBM_REQUIRE(code_map, LBM_EINVAL, "lbm_vq_remap_codes_i64: NULL code_map");
+    LBM_REQUIRE((hist_c_or_null == nullptr) == (hist_or_null == nullptr), LBM_EINVAL,
+                "lbm_vq_remap_codes_i64: the two histograms come together or not at all");
+    hipStream_t st = lbm::as_stream(stream);
+    if (N > 0) {
+        LBM_REQUIRE(idx, LBM_EINVAL, "lbm_vq_remap_codes_i64: NULL idx");
+        LBM_REQUIRE(((uintptr_t)idx & 15) == 0, LBM_EINVAL, "lbm_vq_remap_codes_i64: idx must be 16-byte aligned");
+        const int64_t want = ((N >> 1) + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+        hipLaunchKernelGGL(vq_remap_kernel, dim3(blocks), dim3(256), 0, st, idx, N, code_map, Kc);
+        const int rc = lbm::check_launch("lbm_vq_remap_codes_i64");
+        if (rc != LBM_OK) return rc;
+    }
+    if (hist_or_null != nullptr) {
+        hipLaunchKernelGGL(vq_remap_hist_kernel, dim3((unsigned)((Kc + 255) / 256)), dim3(256), 0, st, hist_c_or_null, hist_or_null, code_map, Kc);
+        return lbm::check_launch("lbm_vq_remap_codes_i64");
+    }
+    return LBM_OK;
+}
+
 extern "C" int lbm_perplexity_u64(const unsigned long long* hist, float* out, int32_t K, lbm_stream_t stream) {
     LBM_REQUIRE(K >= 1 && hist && out, LBM_EINVAL, "lbm_perplexity_u64: bad arguments");
     hipLaunchKernelGGL(perplexity_kernel, dim3(1), dim3(256), 0, lbm::as_stream(stream), hist, out, K);

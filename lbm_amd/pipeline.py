@@ -52,6 +52,9 @@ class PipelineConfig:
     fuse_post: bool = True             # ICA affine + baseline / reject / z-score in one kernel (lbm_affine_post_f32) and Welch on the
                                        # z-scored epochs with the per-row scale (lbm_welch_scaled_f32): 900 000 instead of
                                        # 1 260 000 B of HBM traffic per 30x1500 epoch in the DSP front; False = the separate kernels
+    dedup_codes: bool = True           # search the codebook without the rows that repeat an earlier row bit for bit (a first-minimum
+                                       # argmin can never return them; quantizer.dedup_codebook) and map the tokens back: identical
+                                       # tokens and histogram, fewer code tiles (the shipped codebook: 413 of 512 rows, 7 tiles of 8)
     fold_projection: bool = False      # tokens from the 3rd encoder layer with the last 1x1 conv folded into the codebook
                                        # (quantizer.fold_projection; no z output; equal tokens except fp32 near-ties)
 
@@ -97,10 +100,19 @@ class EpochPipeline:
                 self.cb_fold, self.ee_fold = fold_projection(self.codebook, self.enc["encoder.6.weight"], self.enc["encoder.6.bias"])
             if cfg.vq_method not in ("fp32", "bf16x6", "screen"):
                 raise ValueError(f"vq_method {cfg.vq_method!r}")
+            # what the search runs on: the (folded) codebook, without repeated rows if asked
+            self.cb_used, self.ee_used = (self.cb_fold, self.ee_fold) if cfg.fold_projection else (self.codebook, self.ee)
+            self.K_used, self.K_real, self.code_map = self.K, self.K, None
+            if cfg.dedup_codes:
+                from .quantizer import dedup_codebook
+                r = dedup_codebook(self.cb_used, self.ee_used)
+                if r is not None:
+                    self.cb_used, self.ee_used, self.code_map, self.K_real = r
+                    self.K_used = int(self.cb_used.shape[0])
             self.vq_tab = None
             if cfg.vq_method in ("bf16x6", "screen"):
                 from .quantizer import vq_split_tables
-                self.vq_tab = vq_split_tables(self.cb_fold if cfg.fold_projection else self.codebook)
+                self.vq_tab = vq_split_tables(self.cb_used)
             if cfg.conv_method not in ("fp32", "bf16x6"):
                 raise ValueError(f"conv_method {cfg.conv_method!r}")
             if cfg.conv_k4s2 not in ("wino", "direct"):
@@ -147,10 +159,12 @@ class EpochPipeline:
             # encoder activations: rows padded to a multiple of 4 floats, so every conv access is a 16-byte one
             B.update(h1=mk(E, 64, self.P1), h2=mk(E, 128, self.P2), h3=mk(E, 256, self.P2),
                      tokens=mk(E, self.S, dt=torch.int64), hist=torch.zeros((self.K,), dtype=torch.int64, device=d))
+            if self.code_map is not None:
+                B.update(hist_c=torch.zeros((self.K_used,), dtype=torch.int64, device=d))
             if not c.fold_projection:
                 B.update(z=mk(E, self.D, self.P2))
             if c.vq_method == "screen":
-                B.update(vq_ws=mk(int(self.lib.lbm_vq_screen_workspace_bytes(E * self.S, self.K)), dt=torch.uint8))
+                B.update(vq_ws=mk(int(self.lib.lbm_vq_screen_workspace_bytes(E * self.S, self.K_used)), dt=torch.uint8))
         self._buf, self._cap = B, E
 
     def reset_hist(self):
@@ -185,7 +199,7 @@ class EpochPipeline:
         if (C, T) != (c.n_channels, c.n_times):
             raise ValueError(f"expected [E, {c.n_channels}, {c.n_times}], got {tuple(x.shape)}")
         self._reserve(E)
-        B = {k: (v[:E] if k not in ("hist", "vq_ws") else v) for k, v in self._buf.items()}
+        B = {k: (v[:E] if k not in ("hist", "hist_c", "vq_ws") else v) for k, v in self._buf.items()}
         cur = x
         t0 = mark("", None)
         if c.do_filter:
@@ -265,20 +279,27 @@ class EpochPipeline:
             vq = lib.lbm_vq_argmin_f32 if self.vq_tab is None else lib.lbm_vq_argmin_bf16x6_f32
             if c.vq_method == "screen":      # same call shape as the other two; needs the fp32 codebook AND its piece table
                 def vq(x_, ldx_, layout_, S_, _table, ee_, tok_, _mind, hist_, N_, D_, K_, st_):
-                    cb = self.cb_fold if c.fold_projection else self.codebook
-                    return lib.lbm_vq_argmin_screened_f32(x_, ldx_, layout_, S_, p(cb), p(self.vq_tab), ee_, tok_, hist_, p(B["vq_ws"]),
-                                                          N_, D_, K_, st_)
+                    return lib.lbm_vq_argmin_screened_f32(x_, ldx_, layout_, S_, p(self.cb_used), p(self.vq_tab), ee_, tok_, hist_,
+                                                          p(B["vq_ws"]), N_, D_, K_, st_)
+            hist_k = B["hist_c"] if self.code_map is not None else B["hist"]
+
+            def remap():     # searched rows -> the caller's code numbers (tokens in place, counts into the full histogram)
+                if self.code_map is not None:
+                    _lib.check(lib.lbm_vq_remap_codes_i64(p(B["tokens"]), E * self.S, p(self.code_map), self.K_real, p(hist_k), p(B["hist"]),
+                                                          st), "vq remap")
             if c.fold_projection:
                 _lib.check(vq(p(B["h3"]), self.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, self.S,
-                              p(self.cb_fold if self.vq_tab is None else self.vq_tab), p(self.ee_fold), p(B["tokens"]), None,
-                              p(B["hist"]), E * self.S, self.cb_fold.shape[1], self.K, st), "vq(folded)")
+                              p(self.cb_used if self.vq_tab is None else self.vq_tab), p(self.ee_used), p(B["tokens"]), None,
+                              p(hist_k), E * self.S, self.cb_used.shape[1], self.K_used, st), "vq(folded)")
+                remap()
                 t0 = mark("vq", t0)
                 out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"])
                 return out
             conv(B["h3"], self.P2, B["z"], self.P2, 6, 256, self.L2, self.D, 1, 1, 0, 0)
             t0 = mark("conv4", t0)
-            _lib.check(vq(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.codebook if self.vq_tab is None else self.vq_tab),
-                          p(self.ee), p(B["tokens"]), None, p(B["hist"]), E * self.S, self.D, self.K, st), "vq")
+            _lib.check(vq(p(B["z"]), self.P2, _lib.VQ_CHANNEL_MAJOR, self.S, p(self.cb_used if self.vq_tab is None else self.vq_tab),
+                          p(self.ee_used), p(B["tokens"]), None, p(hist_k), E * self.S, self.D, self.K_used, st), "vq")
+            remap()
             t0 = mark("vq", t0)
             out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"][:, :, :self.S])
         return out

@@ -46,6 +46,34 @@ def fold_projection(codebook, proj_weight, proj_bias=None):
     return (E @ W).to(torch.float32).contiguous().to(dev), c.to(torch.float32).contiguous().to(dev)
 
 
+def dedup_codebook(codebook: torch.Tensor, e_sqnorm: torch.Tensor, pad_to: int = 64):
+    """The sub-codebook a first-minimum search actually needs.
+
+    ``get_code_indices`` (training/model.py:152-158) returns the FIRST minimum, so a row that repeats an earlier row bit for bit --
+    value and ``e_sqnorm`` alike -- can never be returned, whatever the input.  (The shipped checkpoint has 100 all-zero rows among its
+    512: codes the EMA never used.)  Returns ``None`` if no row repeats, else ``(codebook_c [Kp, D], e_sqnorm_c [Kp], code_map [Kp]
+    int64, Kc)``: the first occurrences in ascending order (ties keep resolving to the lowest original index), padded to a multiple of
+    ``pad_to`` rows with codes that never win (zero rows, |e|^2 = 3e38); ``code_map[k]`` is searched row k's original number (padding:
+    0, never produced).  Search with (codebook_c, e_sqnorm_c), then ``lbm_vq_remap_codes_i64`` -- tokens and histogram come out
+    exactly as from the full codebook."""
+    cb = codebook.detach().to("cpu", torch.float32).contiguous().numpy()
+    ee = e_sqnorm.detach().to("cpu", torch.float32).contiguous().numpy()
+    K, D = cb.shape
+    key = np.concatenate([cb.view(np.uint32), ee.view(np.uint32)[:, None]], axis=1)
+    _, first = np.unique(key, axis=0, return_index=True)
+    if first.size == K:
+        return None
+    first = np.sort(first)
+    Kc = int(first.size)
+    Kp = -(-Kc // pad_to) * pad_to
+    cbc = np.zeros((Kp, D), np.float32)
+    eec = np.full((Kp,), 3e38, np.float32)
+    cmap = np.zeros((Kp,), np.int64)
+    cbc[:Kc], eec[:Kc], cmap[:Kc] = cb[first], ee[first], first
+    dev = codebook.device
+    return torch.from_numpy(cbc).to(dev), torch.from_numpy(eec).to(dev), torch.from_numpy(cmap).to(dev), Kc
+
+
 @_lib.on_tensor_device
 def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
     """Device table of the codebook cut into three bf16 pieces per value (``lbm_vq_split_tables_init``), the form

@@ -1206,6 +1206,50 @@ def test_pipeline_k4s2_wino_tokens_are_the_direct_layers_tokens(shipped):
         mk("fast")
 
 
+@pytest.mark.parametrize("vq_method,fold", [("screen", True), ("fp32", False), ("bf16x6", True)])
+def test_pipeline_dedup_codes_changes_nothing(shipped, vq_method, fold):
+    """PipelineConfig.dedup_codes (default): the search runs on the codebook without the rows that repeat an earlier row bit for bit --
+    100 all-zero rows of the shipped checkpoint's 512 -- and lbm_vq_remap_codes_i64 translates tokens and histogram back.  A
+    first-minimum argmin (training/model.py:152-158) can never return a repeated row, so EVERYTHING must equal the full search: tokens
+    and histogram bit for bit, on the shipped codebook, on one whose repeated rows are scattered (a late first occurrence, repeats in
+    front of and behind other codes), with inputs that sit ON the repeated rows, and with no repeats at all (nothing to do)."""
+    from lbm_amd.quantizer import dedup_codebook
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    rs = np.random.RandomState(5)
+    scattered = (np.asarray(synth_codebook(512, 256)) * 0.3).astype(np.float32)
+    scattered[[3, 77, 400, 511]] = scattered[200]          # first occurrence of that row: 3
+    scattered[[10, 11, 12]] = 0.0                          # a run of zero rows
+    scattered[300] = scattered[299]
+    plain = (np.asarray(synth_codebook(512, 256)) * 0.3).astype(np.float32)
+    x = (synth_epochs(40, 30, 1500, seed=23) * 2.0).to(DEV)
+    for name, cb in (("shipped", shipped["vq_layer.embedding.weight"]), ("scattered", scattered), ("plain", plain)):
+        mk = lambda d: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=fold, vq_method=vq_method, dedup_codes=d),  # noqa: E731
+                                             taps, A, b, shipped, cb)
+        full, ded = mk(False), mk(True)
+        assert full.code_map is None
+        if name == "plain":
+            assert ded.code_map is None and ded.K_used == 512
+        else:
+            assert ded.code_map is not None and ded.K_used % 64 == 0 and ded.K_real < 512
+            assert ded.K_real == {"shipped": 413, "scattered": 512 - 4 - 2 - 1}[name]
+        for rep in range(2):      # twice: the searched-row histogram is cleared by the remap, the full one keeps accumulating
+            ref = {k: v.clone() for k, v in full.run(x).items()}
+            out = ded.run(x)
+            assert torch.equal(out["tokens"], ref["tokens"]), name
+            assert torch.equal(out["hist"], ref["hist"]), name
+            assert int(out["hist"].sum()) == (rep + 1) * x.shape[0] * ded.S
+    # rows that ARE repeated codes: the lowest original index wins, with and without the shortcut
+    cbd = torch.from_numpy(scattered).to(DEV)
+    ee = (cbd.double() ** 2).sum(1).float()
+    cbc, eec, cmap, kc = dedup_codebook(cbd, ee)
+    xs = cbd[[200, 3, 511, 11, 300, 299, 5]] + 1e-4 * torch.from_numpy(rs.randn(7, 256).astype(np.float32)).to(DEV)
+    tok = lbm_amd.vq_argmin(xs, cbc, eec)
+    assert _lib.load().lbm_vq_remap_codes_i64(_lib.ptr(tok), tok.numel(), _lib.ptr(cmap), kc, None, None, _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert tok.tolist() == lbm_amd.vq_argmin(xs, cbd, ee).tolist() == [3, 3, 3, 10, 299, 299, 5]
+
+
 def test_pipeline_without_cleaned_output(shipped):
     """emit_cleaned=False: no "cleaned" tensor; tokens / keep / standardized identical, PSD equal to fp32 rounding
     (Welch removes each segment's mean, so the baseline offset never reaches it)."""

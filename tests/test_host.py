@@ -190,6 +190,33 @@ def test_vq_screen_workspace_and_arguments():
     assert lib.lbm_vq_argmin_screened_f32(None, 256, 7, 0, None, None, None, None, None, None, 10, 256, 512, None) == -1
 
 
+def test_dedup_codebook_and_remap_arguments():
+    """quantizer.dedup_codebook on the host: first occurrences in ascending order, padding that cannot win, the map back; and the
+    argument checks of lbm_vq_remap_codes_i64 that need no GPU."""
+    import torch
+    from lbm_amd.quantizer import dedup_codebook
+    rs = np.random.RandomState(0)
+    cb = rs.randn(130, 8).astype(np.float32)
+    cb[[5, 90]] = cb[40]                  # first occurrence: 5
+    cb[[0, 129]] = 0.0                    # first occurrence: 0
+    ee = (cb.astype(np.float64) ** 2).sum(1).astype(np.float32)
+    assert dedup_codebook(torch.from_numpy(rs.randn(64, 8).astype(np.float32)), torch.ones(64)) is None
+    cbc, eec, cmap, kc = dedup_codebook(torch.from_numpy(cb), torch.from_numpy(ee))
+    assert kc == 127 and cbc.shape == (128, 8) and eec.shape == (128,) and cmap.shape == (128,) and cmap.dtype == torch.int64
+    first = cmap[:kc].numpy()
+    assert np.all(np.diff(first) > 0) and set(first) == set(range(130)) - {40, 90, 129}
+    assert np.array_equal(cbc[:kc].numpy(), cb[first]) and np.array_equal(eec[:kc].numpy(), ee[first])
+    assert float(eec[kc:].min()) > 1e38 and float(cbc[kc:].abs().max()) == 0.0
+    ee2 = ee.copy(); ee2[90] += 1.0       # same values, another constant: not a repeat (folded codebooks carry their own constants)
+    assert dedup_codebook(torch.from_numpy(cb), torch.from_numpy(ee2))[3] == 128
+    lib = _lib.load()
+    assert lib.lbm_vq_remap_codes_i64(None, 0, None, 4, None, None, None) == -1          # NULL map
+    assert lib.lbm_vq_remap_codes_i64(None, -1, cmap.data_ptr(), 4, None, None, None) == -1
+    assert lib.lbm_vq_remap_codes_i64(None, 5, cmap.data_ptr(), 4, None, None, None) == -1   # NULL idx with N > 0
+    assert lib.lbm_vq_remap_codes_i64(None, 0, cmap.data_ptr(), 4, cmap.data_ptr(), None, None) == -1   # one histogram only
+    assert lib.lbm_vq_remap_codes_i64(None, 0, cmap.data_ptr(), 0, None, None, None) == -1
+
+
 def test_conv_k4s2_wino_arguments():
     """lbm_conv1d_k4s2_wino_f32 argument checks that need no GPU (include/lbm_abi.h)."""
     lib = _lib.load()

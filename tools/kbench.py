@@ -93,8 +93,9 @@ def main():
             torch.cuda.synchronize()
             del xe
             h3, ws, tok = pipe._buf["h3"], pipe._buf["vq_ws"], pipe._buf["tokens"]
-            fn = lambda: lib.lbm_vq_argmin_screened_f32(p(h3), pipe.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, S, p(pipe.cb_fold), p(pipe.vq_tab),  # noqa: E731
-                                                        p(pipe.ee_fold), p(tok), None, p(ws), E * S, 256, 512, st)
+            # (what the pipeline searches: the folded codebook without its repeated rows, PipelineConfig.dedup_codes)
+            fn = lambda: lib.lbm_vq_argmin_screened_f32(p(h3), pipe.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, S, p(pipe.cb_used), p(pipe.vq_tab),  # noqa: E731
+                                                        p(pipe.ee_used), p(tok), None, p(ws), E * S, 256, pipe.K_used, st)
         if s == "vqb":
             tab = lbm_amd.vq_split_tables(cb)
             fn = lambda: lib.lbm_vq_argmin_bf16x6_f32(p(z), PS, _lib.VQ_CHANNEL_MAJOR, S, p(tab), p(ee), p(tok), None, None, E * S, 256, 512, st)  # noqa: E731
