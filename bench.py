@@ -50,10 +50,12 @@ KERNEL_OF_K4S2_DIRECT = {"conv1": "conv_k4s2_ws_kernel<30,2>", "conv2": "conv_k4
 KERNEL_OF_VQ = {"fp32": "vq_argmin_dma_kernel", "bf16x6": "vq_bf16x6_kernel", "screen": "vq_screen_pipe_kernel<1> (+ vq_argmin_kernel<256,1,true> on the unsettled rows)"}
 
 
-def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, vq_method="fp32", conv_k4s2="wino"):
+def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, vq_method="fp32", conv_k4s2="wino", k_searched=None):
     """Algorithmic flops / compulsory HBM bytes per launch of each stage over E epochs (SURVEY.md 8d figures).  `flops` is the
     reference's arithmetic; where a kernel executes something else (Winograd: 2/3 of the products; the screened quantizer: three
-    bf16 piece products per fp32 product on the bf16 matrix cores) `exec_flops` / `peak` say what ran and against which peak."""
+    bf16 piece products per fp32 product on the bf16 matrix cores, over the `k_searched` distinct rows of the codebook)
+    `exec_flops` / `peak` say what ran and against which peak."""
+    Ks = K if k_searched is None else k_searched
     ep = C * T * 4
     # the 4-tap stride-2 layers as two 2-tap phases in F(3,2): 4 products per 3 outputs and phase instead of 6 (where rows are 16-byte
     # pitched and Cin <= 64: what EpochPipeline checks)
@@ -74,7 +76,7 @@ def stage_model(E, C, T, ntaps, K, D, S, L1, F, fft_n=2048, emit_cleaned=False, 
                       bound="mfma"),
         "conv4": dict(flops=2.0 * D * 256 * S * E, bytes=(256 * S * 4 + D * S * 4) * E, bound="mfma"),
         "vq": dict(flops=2.0 * S * K * D * E, bytes=(D * S * 4 + S * 8) * E, bound="mfma",
-                   **({"exec_flops": {"screen": 3.0, "bf16x6": 6.0}[vq_method] * 2.0 * S * K * D * E, "peak": PEAK_BF16_TFLOPS}
+                   **({"exec_flops": {"screen": 3.0, "bf16x6": 6.0}[vq_method] * 2.0 * S * Ks * D * E, "peak": PEAK_BF16_TFLOPS}
                       if vq_method in ("screen", "bf16x6") else {})),
     }
 
@@ -223,7 +225,7 @@ def extra_configs(dev, taps, A, b, weights):
     for name, s_, e_ in p5.stage_events:
         acc.setdefault(name, []).append(s_.elapsed_time(e_))
     p5.stage_events = None
-    m5 = stage_model(ch5, C5, T5, len(taps5), K5, 256, p5.S, p5.L1, p5.F, 3 * 4096, vq_method="screen")
+    m5 = stage_model(ch5, C5, T5, len(taps5), K5, 256, p5.S, p5.L1, p5.F, 3 * 4096, vq_method="screen", k_searched=p5.K_used)
     out["config5"] = {"workload": "16 384 synthetic 64ch x 1 kHz x 10 s epochs, K=8192 codebook, full pipeline (folded projection, screened search), chunks of 1024 "
                                   "(one resident 1024-epoch buffer re-walked)",
                       "epochs_per_s": round(E5 / (ms5 * 1e-3), 1), "ms": round(ms5, 2), "stages": stage_report(acc, m5),
@@ -672,7 +674,7 @@ def run_rank(args):
         pipe.stage_events = None
         fft_n = 2048 if args.shape == "S" else 3 * 4096
         model = stage_model(chunk, C, T, len(taps), K, D, S, pipe.L1, F, fft_n, emit_cleaned=args.emit_cleaned, vq_method=args.vq,
-                            conv_k4s2=args.conv_k4s2)
+                            conv_k4s2=args.conv_k4s2, k_searched=pipe.K_used)
         stages = stage_report(acc, model)
 
     # the screened quantizer against the fp32 search it stands for: EVERY token of one whole step (all chunks of the job, walked as

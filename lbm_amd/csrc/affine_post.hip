@@ -32,7 +32,9 @@ __global__ __launch_bounds__(64 * kMaxWaves) void affine_post_kernel(const float
                                                                      uint8_t* __restrict__ keep, int Cin, int Cout, int T, int nb,
                                                                      float thresh, int do_std, float eps) {
     __shared__ float s_part[2][kMaxWaves][32][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // (the wave number through readfirstlane: hipcc then knows that everything derived from it is wave-uniform -- tile-in-range tests
+    // become scalar branches instead of per-lane compares and selects)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int64_t e = blockIdx.x;
     const int o = blockIdx.y * 32 + j;          // this lane's output channel
@@ -66,14 +68,19 @@ __global__ __launch_bounds__(64 * kMaxWaves) void affine_post_kernel(const float
 
     // A operand: lane (j, h) of k-step q reads x[e][c0c(q) + h][t0 + j]; samples past T are clamped to the row's last one (they land
     // in output rows that are never used).  Offsets inside the epoch are 32-bit (Cin * T < 2^31 is checked by the host).
+    // The lane part of an address is an UNSIGNED 32-bit byte offset next to a scalar row base: the load's own "scalar base + 32-bit lane
+    // offset" form, no 64-bit per-lane add per load (Cin * T * 4 < 2^32: host check).
     const float* xe = x + e * (int64_t)Cin * T;
-    int toff[NT];
+    unsigned toff[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         const int t = tw0 + 32 * i + j;
-        toff[i] = hrow * T + (t < T ? t : T - 1);
+        toff[i] = 4u * (unsigned)(hrow * T + (t < T ? t : T - 1));
     }
-    constexpr int G = 4;                          // k-steps per load group: G*NT loads in flight per lane, double buffered
+#ifndef LBM_AP_G
+#define LBM_AP_G 4
+#endif
+    constexpr int G = LBM_AP_G;                   // k-steps per load group: G*NT loads in flight per lane, double buffered
     constexpr int NG = KCH * 16 / G;
     float xv[2][G][NT];
     auto load_group = [&](int g, float (&dst)[G][NT]) {
@@ -82,7 +89,11 @@ __global__ __launch_bounds__(64 * kMaxWaves) void affine_post_kernel(const float
             const int q = g * G + u;
             const float* xr = xe + (int64_t)(2 * q < cmax2 ? 2 * q : cmax2) * T;   // scalar
 #pragma unroll
-            for (int i = 0; i < NT; ++i) dst[u][i] = xr[toff[i]];
+#if defined(LBM_AP_ABLATE) && (LBM_AP_ABLATE & 4)        // timing experiment: no loads
+            for (int i = 0; i < NT; ++i) dst[u][i] = __int_as_float((int)(size_t)xr + (int)toff[i]) * 1e-30f;
+#else
+            for (int i = 0; i < NT; ++i) dst[u][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(xr) + toff[i]);
+#endif
         }
     };
     load_group(0, xv[0]);
@@ -98,23 +109,45 @@ __global__ __launch_bounds__(64 * kMaxWaves) void affine_post_kernel(const float
         __builtin_amdgcn_sched_barrier(0);       // ... and are not sunk below it
     }
 
-    // accumulator register r of tile i = time tw0 + 32 i + 8 (r / 4) + 4 h + (r % 4), channel o
+    // accumulator register r of tile i = time tw0 + 32 i + 8 (r / 4) + 4 h + (r % 4), channel o.  Whether a tile lies inside the row (and
+    // inside the baseline) as a whole, not at all, or in part is wave-uniform: only the one ragged tile of a row pays for per-sample
+    // selects (round 3: the selects and compares of every tile were 700 of the kernel's 2 200 vector instructions per wave).  Sums
+    // run in the same order with or without the selects: same bits.
     const int tl0 = tw0 + 4 * h;
     float vsum = 0.f, bsum = 0.f, vmin = INFINITY, vmax = -INFINITY;
-    const bool wave_full = tw0 + NT * 32 <= T;   // uniform per wave: no time masks needed
-    const bool wave_in_base = tw0 < nb;          // uniform: this wave holds baseline samples
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+        const int ts = tw0 + 32 * i;             // first sample of the tile (uniform)
+        if (ts + 32 <= T) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = tl0 + 32 * i + 8 * (r >> 2) + (r & 3);
-            const float v = acc[i][r];
-            const bool ok = wave_full || t < T;
-            vsum += ok ? v : 0.f;
-            vmin = fminf(vmin, ok ? v : INFINITY);
-            vmax = fmaxf(vmax, ok ? v : -INFINITY);
-            if (wave_in_base) bsum += (t < nb) ? v : 0.f;        // nb <= T
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[i][r];
+                vsum += v;
+                vmin = fminf(vmin, v);
+                vmax = fmaxf(vmax, v);
+            }
+        } else if (ts < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tl0 + 32 * i + 8 * (r >> 2) + (r & 3);
+                const float v = acc[i][r];
+                const bool ok = t < T;
+                vsum += ok ? v : 0.f;
+                vmin = fminf(vmin, ok ? v : INFINITY);
+                vmax = fmaxf(vmax, ok ? v : -INFINITY);
+            }
         }
+        if (ts + 32 <= nb) {                     // nb <= T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += acc[i][r];
+        } else if (ts < nb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tl0 + 32 * i + 8 * (r >> 2) + (r & 3);
+                bsum += (t < nb) ? acc[i][r] : 0.f;
+            }
+        }
+    }
     vsum += __shfl_xor(vsum, 32, 64);
     bsum += __shfl_xor(bsum, 32, 64);
     vmin = fminf(vmin, __shfl_xor(vmin, 32, 64));
@@ -138,13 +171,23 @@ __global__ __launch_bounds__(64 * kMaxWaves) void affine_post_kernel(const float
     float ss = 0.f;
     const float shift = base + mean;
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i) {
+        const int ts = tw0 + 32 * i;
+        if (ts + 32 <= T) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = tl0 + 32 * i + 8 * (r >> 2) + (r & 3);
-            const float d = acc[i][r] - shift;
-            ss = fmaf((wave_full || t < T) ? d : 0.f, d, ss);
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[i][r] - shift;
+                ss = fmaf(d, d, ss);
+            }
+        } else if (ts < T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tl0 + 32 * i + 8 * (r >> 2) + (r & 3);
+                const float d = acc[i][r] - shift;
+                ss = fmaf(t < T ? d : 0.f, d, ss);
+            }
         }
+    }
     float denom = 1.f;
     if (do_std) {
         ss += __shfl_xor(ss, 32, 64);
@@ -171,6 +214,13 @@ __global__ __launch_bounds__(64 * kMaxWaves) void affine_post_kernel(const float
                 vs[u] = (acc[i][4 * rq + u] - shift) * inv;
             }
             if constexpr (VEC) {                 // T % 4 == 0 and 16-byte aligned outputs: a quad is in range as a whole
+#if defined(LBM_AP_ABLATE) && (LBM_AP_ABLATE & 1)      // timing experiment (results garbage): the same stores, 1 KiB per wave-instruction
+                if (do_std) *reinterpret_cast<float4*>(y_std + e * (int64_t)Cout * T + ((wave * NT + i) * 4 + rq) * 256 + lane * 4) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+                continue;
+#elif defined(LBM_AP_ABLATE) && (LBM_AP_ABLATE & 2)    // timing experiment: no stores
+                if (vs[0] == 1.2345f) y_std[0] = vb[0];
+                continue;
+#endif
                 if (y_base != nullptr) *reinterpret_cast<float4*>(y_base + rowoff + t) = make_float4(vb[0], vb[1], vb[2], vb[3]);
                 if (do_std) *reinterpret_cast<float4*>(y_std + rowoff + t) = make_float4(vs[0], vs[1], vs[2], vs[3]);
             } else {
