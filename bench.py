@@ -570,11 +570,11 @@ def run_rank(args):
         host_ring = [x[:chunk].cpu().pin_memory() for _ in range(2)]
         dev_ring = [torch.empty((chunk, C, T), dtype=torch.float32, device=dev) for _ in range(2)]
 
-    def store(lo, n, out):
+    def dest(lo, n):      # the chunk's slices of the job-wide arrays: the kernels write PSD, band features and keep mask there directly
+        return {"psd": psd[lo:lo + n], "bandpower": bp[lo:lo + n], "keep": keep[lo:lo + n]}
+
+    def store(lo, n, out):      # tokens: int64 at the API, int16 / int32 in the job-wide array
         tokens[lo:lo + n].copy_(out["tokens"])
-        psd[lo:lo + n].copy_(out["psd"])
-        bp[lo:lo + n].copy_(out["bandpower"])
-        keep[lo:lo + n].copy_(out["keep"])
 
     def step_from_host():
         pipe.reset_hist()
@@ -594,7 +594,7 @@ def run_rank(args):
             torch.cuda.current_stream().wait_event(ready[cur])
             lo = i * chunk
             n = min(chunk, E - lo)
-            out = pipe.run(dev_ring[cur][:n])
+            out = pipe.run(dev_ring[cur][:n], out=dest(lo, n))
             freed[cur].record()
             store(lo, n, out)
         return pipe._buf["hist"]
@@ -613,7 +613,7 @@ def run_rank(args):
             src = lo % R
             if src + n > R:
                 src = R - n
-            store(lo, n, pipe.run(x[src:src + n]))
+            store(lo, n, pipe.run(x[src:src + n], out=dest(lo, n)))
             if xch is not None and i in group_end:
                 xch.gather_group(g_lo, lo + n)        # this group's exchange rides under the next group's kernels
                 g_lo = lo + n

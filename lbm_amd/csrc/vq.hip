@@ -534,19 +534,27 @@ extern "C" int lbm_vq_gather_loss_f32(const float* x, const float* codebook, con
 
 namespace {
 
-// idx[i] <- code_map[idx[i]]: tokens of a searched sub-codebook back to the caller's code numbers (16 bytes = two tokens per access)
-__global__ __launch_bounds__(256) void vq_remap_kernel(int64_t* __restrict__ idx, int64_t N, const int64_t* __restrict__ code_map, int Kc) {
+// idx[i] <- code_map[idx[i]]: tokens of a searched sub-codebook back to the caller's code numbers (16 bytes = two tokens per access;
+// `head` = 1 when idx itself is only 8-byte aligned: its first token is then mapped alone and the pairs start behind it)
+__global__ __launch_bounds__(256) void vq_remap_kernel(int64_t* __restrict__ idx, int64_t N, const int64_t* __restrict__ code_map, int Kc, int head) {
     const int64_t stride = (int64_t)gridDim.x * 256;
-    const int64_t pairs = N >> 1;
+    int64_t* body = idx + head;
+    const int64_t nb = N - head, pairs = nb >> 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
-        longlong2 v = reinterpret_cast<longlong2*>(idx)[i];
+        longlong2 v = reinterpret_cast<longlong2*>(body)[i];
         v.x = (v.x >= 0 && v.x < Kc) ? code_map[v.x] : v.x;
         v.y = (v.y >= 0 && v.y < Kc) ? code_map[v.y] : v.y;
-        reinterpret_cast<longlong2*>(idx)[i] = v;
+        reinterpret_cast<longlong2*>(body)[i] = v;
     }
-    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t v = idx[N - 1];
-        if (v >= 0 && v < Kc) idx[N - 1] = code_map[v];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) {
+            const int64_t v = idx[0];
+            if (v >= 0 && v < Kc) idx[0] = code_map[v];
+        }
+        if (nb & 1) {
+            const int64_t v = body[nb - 1];
+            if (v >= 0 && v < Kc) body[nb - 1] = code_map[v];
+        }
     }
 }
 
@@ -573,10 +581,11 @@ extern "C" int lbm_vq_remap_codes_i64(int64_t* idx, int64_t N, const int64_t* co
     hipStream_t st = lbm::as_stream(stream);
     if (N > 0) {
         LBM_REQUIRE(idx, LBM_EINVAL, "lbm_vq_remap_codes_i64: NULL idx");
-        LBM_REQUIRE(((uintptr_t)idx & 15) == 0, LBM_EINVAL, "lbm_vq_remap_codes_i64: idx must be 16-byte aligned");
+        LBM_REQUIRE(((uintptr_t)idx & 7) == 0, LBM_EINVAL, "lbm_vq_remap_codes_i64: idx must be 8-byte aligned");
+        const int head = ((uintptr_t)idx & 15) ? 1 : 0;
         const int64_t want = ((N >> 1) + 255) / 256;
         const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
-        hipLaunchKernelGGL(vq_remap_kernel, dim3(blocks), dim3(256), 0, st, idx, N, code_map, Kc);
+        hipLaunchKernelGGL(vq_remap_kernel, dim3(blocks), dim3(256), 0, st, idx, N, code_map, Kc, head);
         const int rc = lbm::check_launch("lbm_vq_remap_codes_i64");
         if (rc != LBM_OK) return rc;
     }

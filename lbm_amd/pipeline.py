@@ -172,15 +172,29 @@ class EpochPipeline:
             self._buf["hist"].zero_()
 
     # ------------------------------------------------------------------ one chunk
-    def run(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+    # caller-owned outputs run() can write in place of its own buffers: name -> (buffer key, dtype, trailing shape)
+    def _out_specs(self):
+        c = self.cfg
+        specs = {"psd": ("psd", torch.float32, (c.n_channels, self.F)), "bandpower": ("bp", torch.float32, (6,)),
+                 "keep": ("keep", torch.uint8, ())}
+        if c.do_tokenize:
+            specs["tokens"] = ("tokens", torch.int64, (self.S,))
+        return specs
+
+    def run(self, x: torch.Tensor, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """x: [E, C, T] float32 CUDA tensor on the pipeline's device.  Returns views into the pipeline's buffers (valid
-        until the next run).  Kernels are enqueued on that device's current stream."""
+        until the next run).  Kernels are enqueued on that device's current stream.
+
+        ``out``: optional caller-owned destinations for "tokens" [E, S] int64, "psd" [E, C, F] float32, "bandpower" [E, 6]
+        float32 and / or "keep" [E] uint8 -- contiguous tensors on the pipeline's device, e.g. the slice of a job-wide array
+        this chunk belongs to.  The kernels then write there directly (no copy afterwards) and the returned dict holds
+        those tensors."""
         if x.is_cuda and x.device != self.dev:
             raise ValueError(f"x lives on {x.device}, the pipeline on {self.dev}")
         with torch.cuda.device(self.dev):
-            return self._run(x)
+            return self._run(x, out)
 
-    def _run(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def _run(self, x: torch.Tensor, out_bufs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         c, lib, p, st = self.cfg, self.lib, _lib.ptr, _lib.stream_ptr()
         ev = self.stage_events
 
@@ -200,6 +214,16 @@ class EpochPipeline:
             raise ValueError(f"expected [E, {c.n_channels}, {c.n_times}], got {tuple(x.shape)}")
         self._reserve(E)
         B = {k: (v[:E] if k not in ("hist", "hist_c", "vq_ws") else v) for k, v in self._buf.items()}
+        if out_bufs:
+            specs = self._out_specs()
+            for name, t in out_bufs.items():
+                if name not in specs:
+                    raise ValueError(f"out[{name!r}]: this pipeline can write {sorted(specs)} into caller-owned tensors")
+                key, dt, tail = specs[name]
+                if (not isinstance(t, torch.Tensor) or t.device != self.dev or t.dtype != dt or tuple(t.shape) != (E,) + tail
+                        or not t.is_contiguous()):
+                    raise ValueError(f"out[{name!r}] must be a contiguous {dt} tensor of shape {(E,) + tail} on {self.dev}")
+                B[key] = t
         cur = x
         t0 = mark("", None)
         if c.do_filter:

@@ -1250,6 +1250,39 @@ def test_pipeline_dedup_codes_changes_nothing(shipped, vq_method, fold):
     assert tok.tolist() == lbm_amd.vq_argmin(xs, cbd, ee).tolist() == [3, 3, 3, 10, 299, 299, 5]
 
 
+def test_pipeline_writes_into_caller_owned_outputs(shipped):
+    """EpochPipeline.run(x, out=...): tokens / PSD / band features / keep mask land in the caller's tensors (here: odd-offset slices of
+    larger arrays, so the token slice is only 8-byte aligned), bit-identical to the pipeline's own buffers; wrong shapes, dtypes, devices
+    and names are refused before anything is launched."""
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    pipe = lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=True, vq_method="screen"), taps, A, b, shipped,
+                                 shipped["vq_layer.embedding.weight"])
+    assert pipe.code_map is not None          # the remap pass runs on the caller's token slice
+    E, lo = 37, 3
+    x = (synth_epochs(E, 30, 1500, seed=31) * 2.0).to(DEV)
+    x[5, 3] += 400e-6 * torch.sin(2 * math.pi * 10.0 * torch.arange(1500, device=DEV) / 500.0)     # an in-band swing: epoch 5 is rejected
+    ref = {k: v.clone() for k, v in pipe.run(x).items()}
+    big = {"tokens": torch.full((E + 8, pipe.S), -7, dtype=torch.int64, device=DEV),
+           "psd": torch.full((E + 8, 30, pipe.F), -7.0, device=DEV), "bandpower": torch.full((E + 8, 6), -7.0, device=DEV),
+           "keep": torch.full((E + 8,), 9, dtype=torch.uint8, device=DEV)}
+    dest = {k: v[lo:lo + E] for k, v in big.items()}
+    assert dest["tokens"].data_ptr() % 16 == 8
+    out = pipe.run(x, out=dest)
+    torch.cuda.synchronize()
+    for k in dest:
+        assert out[k].data_ptr() == dest[k].data_ptr()
+        assert torch.equal(dest[k], ref[k]), k
+        assert bool((big[k][:lo] == (9 if k == "keep" else -7)).all()) and bool((big[k][lo + E:] == (9 if k == "keep" else -7)).all()), k
+    assert int(ref["keep"][5]) == 0 and 0 < int(ref["keep"].sum()) < E
+    only = pipe.run(x, out={"psd": dest["psd"]})              # a subset: the rest stays in the pipeline's buffers
+    assert only["psd"].data_ptr() == dest["psd"].data_ptr() and torch.equal(only["tokens"], ref["tokens"])
+    for bad in ({"tokens": dest["tokens"].to(torch.int32)}, {"psd": big["psd"][lo:lo + E + 1]}, {"psd": dest["psd"].cpu()},
+                {"bandpower": big["bandpower"][lo:lo + E, ::2]}, {"standardized": x}):
+        with pytest.raises(ValueError):
+            pipe.run(x, out=bad)
+
+
 def test_pipeline_without_cleaned_output(shipped):
     """emit_cleaned=False: no "cleaned" tensor; tokens / keep / standardized identical, PSD equal to fp32 rounding
     (Welch removes each segment's mean, so the baseline offset never reaches it)."""
