@@ -13,7 +13,7 @@ from .fastica import ica_fit, find_bads_eog, find_bads_ecg, fastica_parallel, ic
 from .epochs import (epoch_post, affine_post, affine_post_supported, standardize_epochs, Scaler, n_baseline_samples, make_epochs,  # noqa: F401
                      save_preprocess_outputs, save_withpsd_outputs)
 from .psd import psd_array_welch, band_powers, classify_eeg_state, classify_eeg_state_variant  # noqa: F401
-from .quantizer import (VectorQuantizerEMA, VQVAE, encode_data_for_transformer, vq_argmin, vq_split_tables, fold_projection, conv_split_tables, conv_wino3_tables, conv1d,  # noqa: F401
+from .quantizer import (VectorQuantizerEMA, VQVAE, encode_data_for_transformer, vq_argmin, vq_split_tables, fold_projection, dedup_codebook, remap_codes, conv_split_tables, conv_wino3_tables, conv1d,  # noqa: F401
                         encoder_forward, rownorm2, vq_gather_loss, perplexity_from_hist, vq_ema_sums, vq_ema_apply)
 from .recording import (read_raw_eeglab, pick_eeg_channels, extract_events, pair_trials, vigilance_labels,  # noqa: F401
                         mne_events, preprocess_recording, preprocess_recording_withpsd,

@@ -75,6 +75,18 @@ def dedup_codebook(codebook: torch.Tensor, e_sqnorm: torch.Tensor, pad_to: int =
 
 
 @_lib.on_tensor_device
+def remap_codes(idx: torch.Tensor, code_map: torch.Tensor, n_codes: int, hist_searched: torch.Tensor = None,
+                hist: torch.Tensor = None) -> torch.Tensor:
+    """In place: indices of a searched sub-codebook (``dedup_codebook``) -> the caller's code numbers (``lbm_vq_remap_codes_i64``);
+    with the two histograms, the counts over searched rows are added into the full histogram and cleared."""
+    if idx.dtype != torch.int64 or not idx.is_contiguous():
+        raise ValueError("remap_codes: idx must be a contiguous int64 tensor")
+    _lib.check(_lib.load().lbm_vq_remap_codes_i64(_lib.ptr(idx), idx.numel(), _lib.ptr(code_map), int(n_codes), _lib.ptr(hist_searched),
+                                                  _lib.ptr(hist), _lib.stream_ptr()), "lbm_vq_remap_codes_i64")
+    return idx
+
+
+@_lib.on_tensor_device
 def vq_split_tables(codebook: torch.Tensor) -> torch.Tensor:
     """Device table of the codebook cut into three bf16 pieces per value (``lbm_vq_split_tables_init``), the form
     ``vq_argmin(..., split_tables=...)`` / ``lbm_vq_argmin_bf16x6_f32`` consume."""
@@ -418,15 +430,34 @@ class VQVAE(nn.Module):
             self._fold_key = key
         return self._fold
 
-    def _screen_tables(self, folded: bool):
-        """bf16 piece table of the (folded) codebook for the screened search, rebuilt when the codebook changes."""
+    def _screen_set(self, folded: bool):
+        """What the screened search runs on, rebuilt when the codebook changes: the (folded) codebook WITHOUT rows that repeat an
+        earlier row bit for bit (``dedup_codebook``: a first-minimum argmin never returns them; the shipped checkpoint has 100
+        all-zero rows), its constants, its bf16 piece table, and the map back to code numbers (None: nothing was dropped)."""
         w = self.vq_layer.embedding.weight
+        if folded:
+            self._folded_codebook()      # refreshes _fold_key
         key = (folded, w.data_ptr(), w._version, str(w.device), self.vq_layer._cb_epoch,
                getattr(self, "_fold_key", None) if folded else None)
         if getattr(self, "_screen_key", None) != key:
-            self._screen_tab = vq_split_tables(self._folded_codebook()[0] if folded else w.detach())
+            cb, ee = self._folded_codebook() if folded else (w.detach(), self.vq_layer._e_sqnorm())
+            r = dedup_codebook(cb, ee)
+            cmap, kc = None, int(cb.shape[0])
+            if r is not None:
+                cb, ee, cmap, kc = r
+            self._screen = (cb, ee, vq_split_tables(cb), cmap, kc)
             self._screen_key = key
-        return self._screen_tab
+        return self._screen
+
+    def _screened_indices(self, h, folded: bool, hist):
+        cb, ee, tab, cmap, kc = self._screen_set(folded)
+        hist_s = hist
+        if cmap is not None and hist is not None:
+            hist_s = torch.zeros((cb.shape[0],), dtype=torch.int64, device=hist.device)
+        idx = vq_argmin(h, cb, ee, channel_major=True, no_xnorm=folded, hist=hist_s, split_tables=tab, screened=True)
+        if cmap is not None:
+            remap_codes(idx, cmap, kc, hist_s if hist is not None else None, hist)
+        return idx
 
     @torch.no_grad()
     @_lib.on_tensor_device
@@ -441,15 +472,15 @@ class VQVAE(nn.Module):
             h = x
             for i, (st, pd) in zip((0, 2, 4), ((2, 1), (2, 1), (1, 1))):
                 h = conv1d(h, self.encoder[i].weight, self.encoder[i].bias, st, pd, True, pitched_out=True)
-            cbf, eef = self._folded_codebook()
-            tab = self._screen_tables(True) if screened else None
-            idx = vq_argmin(h, cbf, eef, channel_major=True, no_xnorm=True, hist=hist, split_tables=tab, screened=screened)
+            if screened:
+                idx = self._screened_indices(h, True, hist)
+            else:
+                cbf, eef = self._folded_codebook()
+                idx = vq_argmin(h, cbf, eef, channel_major=True, no_xnorm=True, hist=hist)
             return idx.view(x.shape[0], -1)
         z = encoder_forward(x, self.encoder, pitched_out=True)
         if screened:
-            vq = self.vq_layer
-            idx = vq_argmin(z.detach(), vq.embedding.weight.detach(), vq._e_sqnorm(), channel_major=True, hist=hist,
-                            split_tables=self._screen_tables(False), screened=True)
+            idx = self._screened_indices(z.detach(), False, hist)
         else:
             idx = self.vq_layer.get_code_indices_channel_major(z, hist=hist)
         return idx.view(x.shape[0], -1)

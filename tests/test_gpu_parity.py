@@ -869,14 +869,23 @@ def test_vqvae_encode_screened_option(shipped, vq_golden):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in shipped.items()}, strict=False)
     m = m.to(DEV).eval()
     x = torch.from_numpy(vq_golden["x_S"]).to(DEV)
+    def same(fold):      # indices AND histogram (accumulating over two calls) of the screened search == the default search's
+        h1 = torch.zeros(512, dtype=torch.int64, device=DEV)
+        h2 = torch.zeros(512, dtype=torch.int64, device=DEV)
+        for _ in range(2):
+            assert torch.equal(m.encode(x, hist=h1, fold_projection=fold, screened=True), m.encode(x, hist=h2, fold_projection=fold))
+        assert torch.equal(h1, h2) and int(h1.sum()) == 2 * x.shape[0] * (x.shape[2] // 4)
     for fold in (False, True):
-        assert torch.equal(m.encode(x, fold_projection=fold, screened=True), m.encode(x, fold_projection=fold))
+        same(fold)
+        # the shipped codebook's 100 all-zero rows are not searched (quantizer.dedup_codebook): 413 distinct rows, padded to 448
+        cb, ee, tab, cmap, kc = m._screen_set(fold)
+        assert (cb.shape[0], kc) == (448, 413) and cmap is not None and int(cmap[:kc].max()) <= 511
     m.train()
     with torch.no_grad():
         m(torch.from_numpy(vq_golden["x_P"]).to(DEV))          # one EMA step rewrites the codebook in place
     m.eval()
     for fold in (False, True):
-        assert torch.equal(m.encode(x, fold_projection=fold, screened=True), m.encode(x, fold_projection=fold))
+        same(fold)
     loader = [(torch.from_numpy(vq_golden["x_S"]), torch.zeros(2, dtype=torch.int64))]
     a, _ = lbm_amd.encode_data_for_transformer(m, loader, DEV, screened=True)
     b, _ = lbm_amd.encode_data_for_transformer(m, loader, DEV)
