@@ -374,7 +374,8 @@ int lbm_vq_ema_apply_f32(float* ema_cluster_size, float* ema_w, float* weight, c
  * rows removed -- the shipped checkpoint has 100 all-zero rows among its 512 -- and translate the indices back.  code_map [Kc] maps a
  * searched row to the caller's code number (ascending, so ties keep resolving to the lowest original index).  In place: idx[i] <-
  * code_map[idx[i]] for 0 <= idx[i] < Kc; with the two histograms, hist[code_map[k]] += hist_c[k] and hist_c[k] <- 0
- * (hist_c: the counts the search accumulated over searched rows; both or neither).  No counterpart in the reference (it searches all rows);
+ * (hist_c: the counts the search accumulated over searched rows); with hist alone (hist_c NULL, Kc <= 12288) the tokens of THIS call are
+ * counted into hist while they are remapped -- the search is then called without a histogram and the tokens are read once less.  No counterpart in the reference (it searches all rows);
  * the host side is lbm_amd.quantizer.dedup_codebook. */
 int lbm_vq_remap_codes_i64(int64_t* idx, int64_t N, const int64_t* code_map, int32_t Kc, unsigned long long* hist_c_or_null,
                            unsigned long long* hist_or_null, lbm_stream_t stream);

@@ -558,6 +558,36 @@ __global__ __launch_bounds__(256) void vq_remap_kernel(int64_t* __restrict__ idx
     }
 }
 
+// The remap above AND the usage histogram in one pass over the tokens: bins over the SEARCHED row (LDS-privatised, as hist_kernel),
+// flushed as hist[code_map[k]] += bin[k].  The grid-stride walk is over 16-byte pairs; the odd head / tail tokens go with thread 0.
+__global__ __launch_bounds__(256) void vq_remap_count_kernel(int64_t* __restrict__ idx, int64_t N, const int64_t* __restrict__ code_map, int Kc,
+                                                             int head, unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned int s_bins[];
+    for (int i = threadIdx.x; i < Kc; i += 256) s_bins[i] = 0u;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t* body = idx + head;
+    const int64_t nb = N - head, pairs = nb >> 1;
+    auto one = [&](int64_t v) -> int64_t {
+        if (v < 0 || v >= Kc) return v;
+        atomicAdd(&s_bins[(int)v], 1u);
+        return code_map[v];
+    };
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += stride) {
+        longlong2 v = reinterpret_cast<longlong2*>(body)[i];
+        v.x = one(v.x);
+        v.y = one(v.y);
+        reinterpret_cast<longlong2*>(body)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head) idx[0] = one(idx[0]);
+        if (nb & 1) body[nb - 1] = one(body[nb - 1]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Kc; i += 256)
+        if (s_bins[i] != 0u) atomicAdd(&hist[code_map[i]], (unsigned long long)s_bins[i]);
+}
+
 // hist[code_map[k]] += hist_c[k]; hist_c[k] <- 0.  code_map is injective on [0, Kc): no two k meet in one bin.
 __global__ __launch_bounds__(256) void vq_remap_hist_kernel(unsigned long long* __restrict__ hist_c, unsigned long long* __restrict__ hist,
                                                             const int64_t* __restrict__ code_map, int Kc) {
@@ -576,9 +606,21 @@ extern "C" int lbm_vq_remap_codes_i64(int64_t* idx, int64_t N, const int64_t* co
                                       unsigned long long* hist_or_null, lbm_stream_t stream) {
     LBM_REQUIRE(N >= 0 && Kc >= 1, LBM_EINVAL, "lbm_vq_remap_codes_i64: bad sizes (N=%lld, Kc=%d)", (long long)N, Kc);
     LBM_REQUIRE(code_map, LBM_EINVAL, "lbm_vq_remap_codes_i64: NULL code_map");
-    LBM_REQUIRE((hist_c_or_null == nullptr) == (hist_or_null == nullptr), LBM_EINVAL,
-                "lbm_vq_remap_codes_i64: the two histograms come together or not at all");
+    LBM_REQUIRE(hist_c_or_null == nullptr || hist_or_null != nullptr, LBM_EINVAL,
+                "lbm_vq_remap_codes_i64: a searched-row histogram needs the full histogram to go to");
     hipStream_t st = lbm::as_stream(stream);
+    if (hist_c_or_null == nullptr && hist_or_null != nullptr) {   // count the tokens of this call while they are remapped
+        LBM_REQUIRE(Kc <= 12288, LBM_EUNSUPPORTED, "lbm_vq_remap_codes_i64: counting supports Kc <= 12288 (got %d): pass the searched-row histogram", Kc);
+        if (N == 0) return LBM_OK;
+        LBM_REQUIRE(idx, LBM_EINVAL, "lbm_vq_remap_codes_i64: NULL idx");
+        LBM_REQUIRE(((uintptr_t)idx & 7) == 0, LBM_EINVAL, "lbm_vq_remap_codes_i64: idx must be 8-byte aligned");
+        const int head = ((uintptr_t)idx & 15) ? 1 : 0;
+        const int64_t want = ((N >> 1) + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+        hipLaunchKernelGGL(vq_remap_count_kernel, dim3(blocks), dim3(256), (size_t)Kc * sizeof(unsigned int), st, idx, N, code_map, Kc, head,
+                           hist_or_null);
+        return lbm::check_launch("lbm_vq_remap_codes_i64");
+    }
     if (N > 0) {
         LBM_REQUIRE(idx, LBM_EINVAL, "lbm_vq_remap_codes_i64: NULL idx");
         LBM_REQUIRE(((uintptr_t)idx & 7) == 0, LBM_EINVAL, "lbm_vq_remap_codes_i64: idx must be 8-byte aligned");

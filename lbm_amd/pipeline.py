@@ -109,6 +109,7 @@ class EpochPipeline:
                 if r is not None:
                     self.cb_used, self.ee_used, self.code_map, self.K_real = r
                     self.K_used = int(self.cb_used.shape[0])
+            self.count_in_remap = True      # (False: the search counts over searched rows, the remap pass moves the counts)
             self.vq_tab = None
             if cfg.vq_method in ("bf16x6", "screen"):
                 from .quantizer import vq_split_tables
@@ -305,7 +306,10 @@ class EpochPipeline:
                 def vq(x_, ldx_, layout_, S_, _table, ee_, tok_, _mind, hist_, N_, D_, K_, st_):
                     return lib.lbm_vq_argmin_screened_f32(x_, ldx_, layout_, S_, p(self.cb_used), p(self.vq_tab), ee_, tok_, hist_,
                                                           p(B["vq_ws"]), N_, D_, K_, st_)
-            hist_k = B["hist_c"] if self.code_map is not None else B["hist"]
+            # with a searched sub-codebook the histogram is taken by the remap pass (one read of the tokens less); beyond its bin limit the
+            # search counts over searched rows into hist_c and the remap pass moves the counts
+            count_in_remap = self.code_map is not None and self.K_real <= 12288 and self.count_in_remap
+            hist_k = None if count_in_remap else (B["hist_c"] if self.code_map is not None else B["hist"])
 
             def remap():     # searched rows -> the caller's code numbers (tokens in place, counts into the full histogram)
                 if self.code_map is not None:

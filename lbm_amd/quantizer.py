@@ -451,13 +451,13 @@ class VQVAE(nn.Module):
 
     def _screened_indices(self, h, folded: bool, hist):
         cb, ee, tab, cmap, kc = self._screen_set(folded)
-        hist_s = hist
-        if cmap is not None and hist is not None:
+        if cmap is None:
+            return vq_argmin(h, cb, ee, channel_major=True, no_xnorm=folded, hist=hist, split_tables=tab, screened=True)
+        hist_s = None            # the remap pass counts the tokens itself (kc <= 12288), else the search counts over searched rows
+        if hist is not None and kc > 12288:
             hist_s = torch.zeros((cb.shape[0],), dtype=torch.int64, device=hist.device)
         idx = vq_argmin(h, cb, ee, channel_major=True, no_xnorm=folded, hist=hist_s, split_tables=tab, screened=True)
-        if cmap is not None:
-            remap_codes(idx, cmap, kc, hist_s if hist is not None else None, hist)
-        return idx
+        return remap_codes(idx, cmap, kc, hist_s, hist)
 
     @torch.no_grad()
     @_lib.on_tensor_device

@@ -213,7 +213,9 @@ def test_dedup_codebook_and_remap_arguments():
     assert lib.lbm_vq_remap_codes_i64(None, 0, None, 4, None, None, None) == -1          # NULL map
     assert lib.lbm_vq_remap_codes_i64(None, -1, cmap.data_ptr(), 4, None, None, None) == -1
     assert lib.lbm_vq_remap_codes_i64(None, 5, cmap.data_ptr(), 4, None, None, None) == -1   # NULL idx with N > 0
-    assert lib.lbm_vq_remap_codes_i64(None, 0, cmap.data_ptr(), 4, cmap.data_ptr(), None, None) == -1   # one histogram only
+    assert lib.lbm_vq_remap_codes_i64(None, 0, cmap.data_ptr(), 4, cmap.data_ptr(), None, None) == -1   # searched-row counts with nowhere to go
+    assert lib.lbm_vq_remap_codes_i64(None, 0, cmap.data_ptr(), 20000, None, cmap.data_ptr(), None) == -2   # counting: Kc <= 12288
+    assert lib.lbm_vq_remap_codes_i64(None, 5, cmap.data_ptr(), 4, None, cmap.data_ptr(), None) == -1       # NULL idx with N > 0, counting mode
     assert lib.lbm_vq_remap_codes_i64(None, 0, cmap.data_ptr(), 0, None, None, None) == -1
 
 
