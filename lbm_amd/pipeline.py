@@ -308,12 +308,14 @@ class EpochPipeline:
                                                           p(B["vq_ws"]), N_, D_, K_, st_)
             # with a searched sub-codebook the histogram is taken by the remap pass (one read of the tokens less); beyond its bin limit the
             # search counts over searched rows into hist_c and the remap pass moves the counts
-            count_in_remap = self.code_map is not None and self.K_real <= 12288 and self.count_in_remap
+            count_in_remap = self.code_map is not None and self.K_used <= 12288 and self.count_in_remap
             hist_k = None if count_in_remap else (B["hist_c"] if self.code_map is not None else B["hist"])
 
             def remap():     # searched rows -> the caller's code numbers (tokens in place, counts into the full histogram)
                 if self.code_map is not None:
-                    _lib.check(lib.lbm_vq_remap_codes_i64(p(B["tokens"]), E * self.S, p(self.code_map), self.K_real, p(hist_k), p(B["hist"]),
+                    # (over all K_used searched rows: a padding row can only "win" where every real score is +inf, and maps to code 0 --
+                    # what the full search returns there)
+                    _lib.check(lib.lbm_vq_remap_codes_i64(p(B["tokens"]), E * self.S, p(self.code_map), self.K_used, p(hist_k), p(B["hist"]),
                                                           st), "vq remap")
             if c.fold_projection:
                 _lib.check(vq(p(B["h3"]), self.P2, _lib.VQ_CHANNEL_MAJOR | _lib.VQ_NO_XNORM, self.S,

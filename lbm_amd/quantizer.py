@@ -453,11 +453,12 @@ class VQVAE(nn.Module):
         cb, ee, tab, cmap, kc = self._screen_set(folded)
         if cmap is None:
             return vq_argmin(h, cb, ee, channel_major=True, no_xnorm=folded, hist=hist, split_tables=tab, screened=True)
-        hist_s = None            # the remap pass counts the tokens itself (kc <= 12288), else the search counts over searched rows
-        if hist is not None and kc > 12288:
-            hist_s = torch.zeros((cb.shape[0],), dtype=torch.int64, device=hist.device)
+        kp = int(cb.shape[0])    # remap over the padding rows too (they map to code 0: what the full search returns where every score is +inf)
+        hist_s = None            # the remap pass counts the tokens itself (kp <= 12288), else the search counts over searched rows
+        if hist is not None and kp > 12288:
+            hist_s = torch.zeros((kp,), dtype=torch.int64, device=hist.device)
         idx = vq_argmin(h, cb, ee, channel_major=True, no_xnorm=folded, hist=hist_s, split_tables=tab, screened=True)
-        return remap_codes(idx, cmap, kc, hist_s, hist)
+        return remap_codes(idx, cmap, kp, hist_s, hist)
 
     @torch.no_grad()
     @_lib.on_tensor_device

@@ -1257,6 +1257,11 @@ def test_pipeline_dedup_codes_changes_nothing(shipped, vq_method, fold):
     assert _lib.load().lbm_vq_remap_codes_i64(_lib.ptr(tok), tok.numel(), _lib.ptr(cmap), kc, None, None, _lib.stream_ptr()) == 0
     torch.cuda.synchronize()
     assert tok.tolist() == lbm_amd.vq_argmin(xs, cbd, ee).tolist() == [3, 3, 3, 10, 299, 299, 5]
+    # a padding row (index >= kc) maps to code 0 when the remap runs over all searched rows, and the counting form agrees
+    tok = torch.tensor([kc, 0, kc + 1, 2, 1], dtype=torch.int64, device=DEV)[1:]            # 8-byte aligned only, odd count
+    h = torch.zeros(512, dtype=torch.int64, device=DEV)
+    lbm_amd.remap_codes(tok, cmap, cbc.shape[0], None, h)
+    assert tok.tolist() == [0, 0, int(cmap[2]), int(cmap[1])] and int(h.sum()) == 4 and int(h[0]) == 2
 
 
 def test_pipeline_writes_into_caller_owned_outputs(shipped):
