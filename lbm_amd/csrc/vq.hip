@@ -13,6 +13,8 @@
 //   ((r&3) + 8*(r>>2) + 4*(lane>>5)), so the running (min, argmin) is a per-lane register update in
 //   ascending code order with strict '<' (first minimum wins); the two lane halves are merged once at
 //   the end with an index tie-break, which reproduces torch.argmin's first-minimum rule exactly.
+#include <atomic>
+
 #include "common.h"
 
 namespace {
@@ -446,8 +448,16 @@ int launch_refine(const float* x, int64_t ldx, int layout, int no_xnorm, int64_t
     if (blocks > 1024) blocks = 1024;
     const int vec_ok = (((uintptr_t)x & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
     auto k = layout == LBM_VQ_ROWS ? vq_argmin_kernel<DP, LBM_VQ_ROWS, true> : vq_argmin_kernel<DP, LBM_VQ_CHANNEL_MAJOR, true>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_screened_f32(refine): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    // (the opt-in to this much dynamic LDS is a per-function, per-device attribute: set once per device, not on every call)
+    static std::atomic<bool> attr_done[2][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+    const int lay = layout == LBM_VQ_ROWS ? 0 : 1;
+    if (dev < 0 || !attr_done[lay][dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return lbm::fail(LBM_ELAUNCH, "lbm_vq_argmin_screened_f32(refine): hipFuncSetAttribute: %s", hipGetErrorString(e));
+        if (dev >= 0) attr_done[lay][dev].store(true, std::memory_order_release);
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, st, x, ldx, codebook, e_sqnorm, idx_out, (float*)nullptr, N, D, K, vec_ok,
                        S, no_xnorm, row_list, row_count);
     return lbm::check_launch("lbm_vq_argmin_screened_f32(refine)");
