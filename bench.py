@@ -312,6 +312,10 @@ def parse_args(argv=None):
                          "(outside the timed region); 0 = all of them")
     ap.add_argument("--conv", choices=["fp32", "bf16x6"], default="fp32",
                     help="256-channel encoder layers: fp32 MFMA kernels (default) or the three-bf16-piece implicit GEMM")
+    ap.add_argument("--overlap-welch", dest="overlap_welch", action="store_true",
+                    help="Welch + band power on a second stream beside the encoder layers, joined before the chunk's outputs are used "
+                         "(PipelineConfig.overlap_welch; default: on the launch stream, in line with the other stages)")
+    ap.set_defaults(overlap_welch=False)
     ap.add_argument("--conv-k4s2", choices=["wino", "direct"], default="wino",
                     help="the two 4-tap stride-2 encoder layers: two 2-tap phases in the minimal form F(3,2) (default; 2/3 of the "
                          "products, fp32 MFMA, same accuracy vs float64) or the direct form")
@@ -534,7 +538,7 @@ def run_rank(args):
     nb = int(round(0.5 * fs)) + 1
     cfg = lbm_amd.PipelineConfig(sfreq=fs, n_channels=C, n_times=T, n_baseline=nb,
                                  fold_projection=args.fold_proj, vq_method=args.vq, conv_method=args.conv,
-                                 conv_k4s2=args.conv_k4s2, emit_cleaned=args.emit_cleaned)
+                                 conv_k4s2=args.conv_k4s2, emit_cleaned=args.emit_cleaned, overlap_welch=args.overlap_welch)
     pipe = lbm_amd.EpochPipeline(cfg, taps, A, b, weights, codebook, device=dev)
     pipe._reserve(chunk)
     S, F = pipe.S, pipe.F
@@ -714,6 +718,7 @@ def run_rank(args):
         base_ms = sum(v["ms"] for v in stages.values())
         for name, kw in (("default_timed_the_same_way", dict(vq_method="screen", fold_projection=True)),   # the first chunk three times, no exchange
                          ("conv_k4s2_direct", dict(vq_method="screen", fold_projection=True, conv_k4s2="direct")),
+                         ("psd_branch_on_a_second_stream", dict(vq_method="screen", fold_projection=True, overlap_welch=True)),
                          ("fp32_search_of_every_row", dict(vq_method="fp32", fold_projection=True)),
                          ("fp32_unfolded_projection", dict(vq_method="fp32", fold_projection=False)),
                          ("vq_bf16x6", dict(vq_method="bf16x6")),
@@ -787,7 +792,7 @@ def run_rank(args):
                                    "%d epochs per step per GPU resident in HBM, walked in chunks of %d"
                                    % ("config3" if args.shape == "S" else "config5", len(taps), K, C, fs, T / fs, E, chunk),
                        "epochs_per_step_per_gpu": E, "resident_epochs_per_gpu": R, "chunk": chunk, "channels": C, "samples": T,
-                       "codebook": K, "codes_searched": int(pipe.K_used), "distinct_codes": int(pipe.K_real), "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "conv_k4s2": args.conv_k4s2, "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
+                       "codebook": K, "codes_searched": int(pipe.K_used), "distinct_codes": int(pipe.K_real), "fold_projection": bool(args.fold_proj), "vq_method": args.vq, "conv_method": args.conv, "conv_k4s2": args.conv_k4s2, "psd_branch": ("second HIP stream beside the encoder layers (PipelineConfig.overlap_welch); the per-stage times are taken with it on the launch stream" if args.overlap_welch else "launch stream"), "emit_cleaned": bool(args.emit_cleaned), "input": "host (PCIe-inclusive)" if args.from_host else "resident in HBM",
                        "outputs": "tokens + PSD + band features + keep mask" + (" + cleaned epochs" if args.emit_cleaned else ""),
                        "collectives": coll, "backend": args.backend if xch is not None else None},
             "roofline": roof,

@@ -52,6 +52,9 @@ class PipelineConfig:
     fuse_post: bool = True             # ICA affine + baseline / reject / z-score in one kernel (lbm_affine_post_f32) and Welch on the
                                        # z-scored epochs with the per-row scale (lbm_welch_scaled_f32): 900 000 instead of
                                        # 1 260 000 B of HBM traffic per 30x1500 epoch in the DSP front; False = the separate kernels
+    overlap_welch: bool = False        # Welch + band power on a second HIP stream beside the encoder's first layers (they need the z-scored
+                                       # rows only; joined before run() returns); ignored while stage events are being recorded.  Measured:
+                                       # -0.05 ms per chunk in a back-to-back walk (profiles/r03_experiments.md), hence off
     dedup_codes: bool = True           # search the codebook without the rows that repeat an earlier row bit for bit (a first-minimum
                                        # argmin can never return them; quantizer.dedup_codebook) and map the tokens back: identical
                                        # tokens and histogram, fewer code tiles (the shipped codebook: 413 of 512 rows, 7 tiles of 8)
@@ -226,6 +229,7 @@ class EpochPipeline:
                     raise ValueError(f"out[{name!r}] must be a contiguous {dt} tensor of shape {(E,) + tail} on {self.dev}")
                 B[key] = t
         cur = x
+        side_done = None
         t0 = mark("", None)
         if c.do_filter:
             if self.fir_tab is not None:
@@ -244,7 +248,22 @@ class EpochPipeline:
                                                p(B["rscale"]) if c.do_tokenize else None, p(B["keep"]), E, C, C, T, c.n_baseline,
                                                float(c.reject), std_mode, c.zscore_eps, st), "affine_post")
             t0 = mark("affine_post", t0)
-            if c.do_tokenize:      # PSD of the cleaned epochs from the z-scored ones: PSD(s x) = s^2 PSD(x), segment means removed
+            if c.do_tokenize and c.overlap_welch and ev is None:
+                # the PSD branch (Welch + band power: latency-bound, 12 waves per CU) on a second stream: it depends on the z-scored rows
+                # only, and its workgroups fit beside the persistent workgroups of the encoder's layers
+                if getattr(self, "_side", None) is None:
+                    self._side = torch.cuda.Stream(device=self.dev)
+                ready = torch.cuda.Event()
+                ready.record()
+                self._side.wait_event(ready)
+                sst = self._side.cuda_stream
+                _lib.check(lib.lbm_welch_scaled_f32(p(B["std"]), p(B["rscale"]), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft,
+                                                    self.n_fft, self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi,
+                                                    _lib.AVG_MEAN, sst), "welch")
+                _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, sst), "bandpower")
+                side_done = torch.cuda.Event()
+                side_done.record(self._side)
+            elif c.do_tokenize:      # PSD of the cleaned epochs from the z-scored ones: PSD(s x) = s^2 PSD(x), segment means removed
                 _lib.check(lib.lbm_welch_scaled_f32(p(B["std"]), p(B["rscale"]), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft,
                                                     self.n_fft, self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi,
                                                     _lib.AVG_MEAN, st), "welch")
@@ -272,7 +291,8 @@ class EpochPipeline:
             _lib.check(lib.lbm_welch_f32(p(base), p(B["psd"]), None, E * C, T, float(c.sfreq), self.n_fft, self.n_fft,
                                          self.n_overlap, p(self.tables), self.bin_lo, self.bin_hi, _lib.AVG_MEAN, st), "welch")
             t0 = mark("welch", t0)
-        _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
+        if side_done is None:
+            _lib.check(lib.lbm_bandpower_f32(p(B["psd"]), p(self.freqs_dev), p(B["bp"]), E, C, self.F, 0, 0, st), "bandpower")
         t0 = mark("bandpower", t0)
         out = {"psd": B["psd"], "bandpower": B["bp"], "keep": B["keep"]}
         if c.emit_cleaned:
@@ -322,6 +342,8 @@ class EpochPipeline:
                               p(self.cb_used if self.vq_tab is None else self.vq_tab), p(self.ee_used), p(B["tokens"]), None,
                               p(hist_k), E * self.S, self.cb_used.shape[1], self.K_used, st), "vq(folded)")
                 remap()
+                if side_done is not None:
+                    torch.cuda.current_stream().wait_event(side_done)
                 t0 = mark("vq", t0)
                 out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"])
                 return out
@@ -332,6 +354,8 @@ class EpochPipeline:
             remap()
             t0 = mark("vq", t0)
             out.update(tokens=B["tokens"], hist=B["hist"], standardized=B["std"], z=B["z"][:, :, :self.S])
+        if side_done is not None:
+            torch.cuda.current_stream().wait_event(side_done)
         return out
 
 

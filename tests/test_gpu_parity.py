@@ -1264,6 +1264,35 @@ def test_pipeline_dedup_codes_changes_nothing(shipped, vq_method, fold):
     assert tok.tolist() == [0, 0, int(cmap[2]), int(cmap[1])] and int(h.sum()) == 4 and int(h[0]) == 2
 
 
+def test_pipeline_psd_branch_on_a_second_stream_changes_nothing(shipped):
+    """PipelineConfig.overlap_welch (an option): Welch + band power run on a second HIP stream beside the encoder layers and are joined
+    before run() returns.  Same outputs bit for bit as in line, over back-to-back runs on different inputs (the buffers are reused while
+    the other stream may still be working), also when the caller's own stream is not the default one and when a consumer on that stream
+    reads the outputs right away."""
+    taps = lbm_amd.create_filter(500.0, 4.0, 30.0)
+    A, b = lbm_amd.ica_projection(**synth_ica(30))
+    mk = lambda ov: lbm_amd.EpochPipeline(lbm_amd.PipelineConfig(fold_projection=True, vq_method="screen", overlap_welch=ov), taps, A, b,  # noqa: E731
+                                          shipped, shipped["vq_layer.embedding.weight"])
+    inline, over = mk(False), mk(True)
+    xs = [(synth_epochs(48, 30, 1500, seed=41 + i) * 2.0).to(DEV) for i in range(3)]
+    want = []
+    for x in xs:
+        o = inline.run(x)
+        want.append({k: o[k].clone() for k in ("tokens", "psd", "bandpower", "keep")})
+    side = torch.cuda.Stream()
+    for stream in (torch.cuda.current_stream(), side):
+        with torch.cuda.stream(stream):
+            got = []
+            for x in xs:                      # no synchronisation between the runs: the copies below are ordered by the stream alone
+                o = over.run(x)
+                got.append({k: o[k].clone() for k in ("tokens", "psd", "bandpower", "keep")})
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            for k in w:
+                assert torch.equal(g[k], w[k]), k
+    assert getattr(over, "_side", None) is not None and getattr(inline, "_side", None) is None
+
+
 def test_pipeline_writes_into_caller_owned_outputs(shipped):
     """EpochPipeline.run(x, out=...): tokens / PSD / band features / keep mask land in the caller's tensors (here: odd-offset slices of
     larger arrays, so the token slice is only 8-byte aligned), bit-identical to the pipeline's own buffers; wrong shapes, dtypes, devices
